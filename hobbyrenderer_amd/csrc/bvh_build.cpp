@@ -1,0 +1,176 @@
+// bvh_build.cpp -- binned-SAH BVH2 over world-space triangles; see bvh_build.h.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace hrt {
+namespace {
+
+struct Prim {
+    float bmin[3], bmax[3], c[3];
+    uint32_t tri;
+};
+struct Box {
+    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+    void grow(const float* a, const float* b) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], a[k]); mx[k] = std::max(mx[k], b[k]); } }
+    void grow(const Box& o) { grow(o.mn, o.mx); }
+    float area() const
+    {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Builder {
+    std::vector<Prim> prims;
+    const std::vector<HostTri>* src = nullptr;
+    BuiltBvh* out = nullptr;
+
+    static int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1)); }
+
+    int32_t make_leaf(uint32_t first, uint32_t count)
+    {
+        uint32_t base = (uint32_t)out->tris.size();
+        for (uint32_t i = 0; i < count; ++i) out->tris.push_back((*src)[prims[first + i].tri]);
+        return encode_leaf(base, count);
+    }
+
+    // returns child reference (>= 0 inner node, < 0 leaf) and its padded bounds
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds)
+    {
+        out->maxDepth = std::max(out->maxDepth, depth);
+        Box b, cb;
+        for (uint32_t i = first; i < first + count; ++i) { b.grow(prims[i].bmin, prims[i].bmax); cb.grow(prims[i].c, prims[i].c); }
+        bounds = b;
+        if (count <= 2) return make_leaf(first, count);
+
+        uint32_t log2c = 0; while ((1u << log2c) < count) ++log2c;
+        bool forceMedian = depth + log2c + 2 >= kTraversalStackDepth;
+
+        int bestAxis = -1; uint32_t bestSplit = 0; float bestCost = 1e30f;
+        constexpr int NB = 16;
+        float leafCost = (float)count * b.area();
+        if (!forceMedian) {
+            for (int axis = 0; axis < 3; ++axis) {
+                float lo = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
+                if (!(ext > 0.0f)) continue;
+                Box bb[NB]; uint32_t bc[NB] = {};
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int bi = std::min(NB - 1, (int)((prims[i].c[axis] - lo) / ext * NB));
+                    bb[bi].grow(prims[i].bmin, prims[i].bmax); bc[bi]++;
+                }
+                float rarea[NB]; uint32_t rcount[NB]; Box acc; uint32_t n = 0;
+                for (int i = NB - 1; i > 0; --i) { acc.grow(bb[i]); n += bc[i]; rarea[i] = acc.area(); rcount[i] = n; }
+                Box lacc; uint32_t ln = 0;
+                for (int i = 0; i < NB - 1; ++i) {
+                    lacc.grow(bb[i]); ln += bc[i];
+                    if (ln == 0 || rcount[i + 1] == 0) continue;
+                    float cost = 1.0f * b.area() + lacc.area() * (float)ln + rarea[i + 1] * (float)rcount[i + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = (uint32_t)i; }
+                }
+            }
+        }
+        if (!forceMedian && count <= kMaxLeafTris && (bestAxis < 0 || bestCost >= leafCost)) return make_leaf(first, count);
+
+        uint32_t mid;
+        if (bestAxis >= 0 && !forceMedian) {
+            float lo = cb.mn[bestAxis], ext = cb.mx[bestAxis] - cb.mn[bestAxis];
+            auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+                int bi = std::min(NB - 1, (int)((p.c[bestAxis] - lo) / ext * NB));
+                return (uint32_t)bi <= bestSplit;
+            });
+            mid = (uint32_t)(it - prims.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        } else {
+            int axis = 0; float e = cb.mx[0] - cb.mn[0];
+            if (cb.mx[1] - cb.mn[1] > e) { axis = 1; e = cb.mx[1] - cb.mn[1]; }
+            if (cb.mx[2] - cb.mn[2] > e) axis = 2;
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count, [axis](const Prim& a, const Prim& c) {
+                if (a.c[axis] != c.c[axis]) return a.c[axis] < c.c[axis];
+                return a.tri < c.tri;
+            });
+        }
+        int32_t id = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        Box lb, rb;
+        int32_t l = build(first, mid - first, depth + 1, lb);
+        int32_t r = build(mid, first + count - mid, depth + 1, rb);
+        HostNode& n = out->nodes[id];
+        for (int k = 0; k < 3; ++k) { n.lmin[k] = lb.mn[k]; n.lmax[k] = lb.mx[k]; n.rmin[k] = rb.mn[k]; n.rmax[k] = rb.mx[k]; }
+        n.left = l; n.right = r; n.pad0 = 0; n.pad1 = 0;
+        return id;
+    }
+};
+
+// mul(float4(p,1), M).xyz in the row-vector convention of Common.hlsli:18-21, left-to-right, no FMA.
+inline void transform_point(const float* p, const float* M, float* o)
+{
+    o[0] = ((p[0] * M[0] + p[1] * M[4]) + p[2] * M[8]) + M[12];
+    o[1] = ((p[0] * M[1] + p[1] * M[5]) + p[2] * M[9]) + M[13];
+    o[2] = ((p[0] * M[2] + p[1] * M[6]) + p[2] * M[10]) + M[14];
+}
+
+} // namespace
+
+bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
+{
+    out = BuiltBvh();
+    if (!s.vertices || !s.indices || !s.meshData || !s.instances || !s.materials || !s.lights) { error = "null scene array"; return false; }
+    if (s.lightCount == 0) { error = "scene needs at least one light (the reference guarantees a directional light, src/Scene.cpp:635-666)"; return false; }
+    for (uint32_t i = 0; i < s.indexCount; ++i)
+        if (s.indices[i] >= s.vertexCount) { error = "index buffer references a vertex out of range"; return false; }
+    uint64_t triCount = 0;
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const HrptPerInstanceData& in = s.instances[i];
+        if (in.m_MeshDataIndex >= s.meshDataCount) { error = "instance m_MeshDataIndex out of range"; return false; }
+        if (in.m_MaterialIndex >= s.materialCount) { error = "instance m_MaterialIndex out of range"; return false; }
+        if (in.m_LODIndex >= 8) { error = "instance m_LODIndex out of range"; return false; }
+        const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
+        if ((uint64_t)md.m_IndexOffsets[0] + md.m_IndexCounts[0] > s.indexCount || md.m_IndexCounts[0] % 3 != 0) { error = "mesh LOD0 index range invalid"; return false; }
+        triCount += md.m_IndexCounts[0] / 3;
+    }
+    if (triCount >= (1ull << 29)) { error = "too many triangles"; return false; }
+
+    std::vector<HostTri> tris; tris.reserve((size_t)triCount);
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const HrptPerInstanceData& in = s.instances[i];
+        const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
+        uint32_t opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+        for (uint32_t p = 0; p < md.m_IndexCounts[0] / 3; ++p) {
+            const uint32_t* ix = s.indices + md.m_IndexOffsets[0] + 3 * (size_t)p;
+            HostTri t;
+            transform_point(s.vertices[ix[0]].m_Pos, in.m_World, t.p0);
+            transform_point(s.vertices[ix[1]].m_Pos, in.m_World, t.p1);
+            transform_point(s.vertices[ix[2]].m_Pos, in.m_World, t.p2);
+            t.inst = i; t.prim = p; t.flags = opaque;
+            tris.push_back(t);
+        }
+    }
+    if (tris.empty()) return true;
+
+    Builder b; b.src = &tris; b.out = &out;
+    b.prims.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); ++i) {
+        Prim& p = b.prims[i]; const HostTri& t = tris[i];
+        for (int k = 0; k < 3; ++k) {
+            float mn = std::min(t.p0[k], std::min(t.p1[k], t.p2[k])), mx = std::max(t.p0[k], std::max(t.p1[k], t.p2[k]));
+            if (!(mn == mn) || !(mx == mx) || std::isinf(mn) || std::isinf(mx)) { error = "non-finite vertex position"; return false; }
+            // conservative padding: the fp32 watertight test can accept points a few ulp outside the triangle
+            float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f;
+            p.bmin[k] = mn - pad; p.bmax[k] = mx + pad; p.c[k] = 0.5f * mn + 0.5f * mx;
+        }
+        p.tri = (uint32_t)i;
+    }
+    out.tris.reserve(tris.size());
+    Box root;
+    int32_t r = b.build(0, (uint32_t)tris.size(), 0, root);
+    if (r < 0) { out.rootLeaf = r; out.nodes.clear(); }
+    return true;
+}
+
+} // namespace hrt

@@ -1,0 +1,47 @@
+// bvh_build.h -- host-side construction of the library-owned acceleration structure that stands in
+// for the driver BLAS/TLAS of Scene::BuildAccelerationStructures (/root/reference/src/Scene.cpp:67-214).
+//
+// MI355X-first choice: no two-level structure. Instance transforms are static on this path
+// (PathTracerRenderer::Render pauses animation, src/PathTracerRenderer.cpp:53), so every triangle is
+// pre-transformed to world space once and a single BVH2 is built over all of them; rays are never
+// re-transformed and a traversal step is one 64-byte read. The contract kept from the reference:
+// triangle p of instance i is indices[m_IndexOffsets[0] + 3p + {0,1,2}] -> vertices[].m_Pos through
+// the instance's world matrix; CommittedInstanceIndex = i, CommittedPrimitiveIndex = p; instances whose
+// material alpha mode is OPAQUE are ForceOpaque, the others raise candidates (src/Scene.cpp:135,150-154).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hobbyrt_pt.h"
+
+namespace hrt {
+
+struct HostNode {           // mirrors hrt::GpuNode (pt_device.h), 64 B
+    float lmin[3]; int32_t left;
+    float lmax[3]; int32_t right;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+struct HostTri {            // mirrors hrt::GpuTri, 48 B
+    float p0[3]; uint32_t inst;
+    float p1[3]; uint32_t prim;
+    float p2[3]; uint32_t flags;
+};
+static_assert(sizeof(HostNode) == 64 && sizeof(HostTri) == 48, "GPU layouts");
+
+struct BuiltBvh {
+    std::vector<HostNode> nodes;    // empty when the scene fits one leaf
+    std::vector<HostTri> tris;      // leaf order
+    int32_t rootLeaf = 0;           // encoded leaf when nodes is empty and tris is not
+    uint32_t maxDepth = 0;
+};
+
+constexpr uint32_t kMaxLeafTris = 4;
+constexpr uint32_t kTraversalStackDepth = 32;   // the builder guarantees depth < this
+
+// Validates every index of the scene description (returns false + message) and builds the BVH.
+bool build_scene_bvh(const HrptSceneDesc& scene, BuiltBvh& out, std::string& error);
+
+} // namespace hrt

@@ -1,0 +1,341 @@
+// pt_capi.cpp -- implementation of the C ABI declared in include/hobbyrt_pt.h. Host code only:
+// context/stream ownership, scene upload (copies), BVH build, per-dispatch constants exactly as
+// PathTracerRenderer::Render fills them (/root/reference/src/PathTracerRenderer.cpp:58-75), launches.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hobbyrt_pt.h"
+#include "bvh_build.h"
+#include "pt_device.h"
+#include "pt_kernels.h"
+#include "pt_wavefront.h"
+
+using namespace hrt;
+
+struct HrptContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    std::vector<void*> allocations;          // scene-lifetime device allocations
+    SceneView view{};
+    bool haveScene = false;
+    uint32_t bvhNodes = 0, bvhTris = 0;
+    // images
+    uint32_t width = 0, height = 0;
+    float4* dAccum = nullptr; float4* dOutput = nullptr;
+    DeviceCounters* dCounters = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+    WavefrontState wf;
+    float traceMs = 0.0f; uint32_t traceLaunches = 0;
+};
+
+static std::mutex g_errMutex;
+static std::string g_createError;
+
+static int fail(HrptContext* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    else { std::lock_guard<std::mutex> l(g_errMutex); g_createError = msg; }
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? HRPT_ERR_OUT_OF_MEMORY : HRPT_ERR_HIP, \
+                                          std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// DirectX::PackedVector::XMConvertFloatToHalf (round to nearest even), src/CommonResources.cpp:553
+static uint16_t float_to_half(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? (0x200u | ((x >> 13) & 0x3ffu)) : 0u));
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        uint32_t shift = 126u - (x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        uint32_t h = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1u);
+        if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t r = x + 0xfffu + ((x >> 13) & 1u);
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+
+static void free_scene(HrptContext* c)
+{
+    for (void* p : c->allocations) (void)hipFree(p);
+    c->allocations.clear();
+    c->haveScene = false;
+    memset(&c->view, 0, sizeof c->view);
+}
+
+template <class T>
+static int upload(HrptContext* c, const T* host, size_t count, const T** dev)
+{
+    *dev = nullptr;
+    size_t bytes = count * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes ? bytes : 16));
+    c->allocations.push_back(p);
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = static_cast<const T*>(p);
+    return HRPT_OK;
+}
+
+extern "C" {
+
+int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
+{
+    if (!desc || !out) return fail(nullptr, HRPT_ERR_INVALID_ARGUMENT, "hrpt_create: null argument");
+    *out = nullptr;
+    if (desc->abiVersion != HRPT_ABI_VERSION) return fail(nullptr, HRPT_ERR_INVALID_ARGUMENT, "hrpt_create: ABI version mismatch");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, HRPT_ERR_NO_DEVICE, "hrpt_create: no HIP device available (the gfx950 kernels are the only backend)");
+    if (desc->deviceOrdinal < 0 || desc->deviceOrdinal >= n) return fail(nullptr, HRPT_ERR_NO_DEVICE, "hrpt_create: device ordinal out of range");
+    HrptContext* c = new HrptContext();
+    c->device = desc->deviceOrdinal;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
+        hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters)) != hipSuccess ||
+        hipMemset(c->dCounters, 0, sizeof(DeviceCounters)) != hipSuccess) {
+        int r = fail(nullptr, HRPT_ERR_HIP, "hrpt_create: stream/event/counter creation failed");
+        delete c;
+        return r;
+    }
+    *out = c;
+    return HRPT_OK;
+}
+
+void hrpt_destroy(HrptContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    wavefront_release(c->wf);
+    if (c->dAccum) (void)hipFree(c->dAccum);
+    if (c->dOutput) (void)hipFree(c->dOutput);
+    if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hrpt_last_error(const HrptContext* c)
+{
+    if (c) return c->err.c_str();
+    std::lock_guard<std::mutex> l(g_errMutex);
+    static thread_local std::string copy;
+    copy = g_createError;
+    return copy.c_str();
+}
+
+int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!s) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: null scene");
+    if (!s->brunetonTransmittance || !s->brunetonScattering) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: Bruneton LUTs missing");
+    if (s->textureCount && !s->textures) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: null texture table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    BuiltBvh bvh; std::string berr;
+    if (!build_scene_bvh(*s, bvh, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    SceneView v{};
+    int r;
+    const HostNode* dn; const HostTri* dt;
+    if ((r = upload(c, bvh.nodes.data(), bvh.nodes.size(), &dn)) != HRPT_OK) return r;
+    if ((r = upload(c, bvh.tris.data(), bvh.tris.size(), &dt)) != HRPT_OK) return r;
+    v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
+    v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
+    v.rootLeaf = bvh.rootLeaf;
+    if ((r = upload(c, s->vertices, s->vertexCount, &v.vertices)) != HRPT_OK) return r;
+    if ((r = upload(c, s->indices, s->indexCount, &v.indices)) != HRPT_OK) return r;
+    v.indexCount = s->indexCount;
+    if ((r = upload(c, s->meshData, s->meshDataCount, &v.meshData)) != HRPT_OK) return r;
+    if ((r = upload(c, s->instances, s->instanceCount, &v.instances)) != HRPT_OK) return r;
+    if ((r = upload(c, s->materials, s->materialCount, &v.materials)) != HRPT_OK) return r;
+    if ((r = upload(c, s->lights, s->lightCount, &v.lights)) != HRPT_OK) return r;
+    v.lightCount = s->lightCount;
+
+    std::vector<GpuTexture> table(s->textureCount);
+    for (uint32_t i = 0; i < s->textureCount; ++i) {
+        table[i].rgba8 = nullptr; table[i].w = s->textures[i].width; table[i].h = s->textures[i].height;
+        if (s->textures[i].rgba8) {
+            if (s->textures[i].width == 0 || s->textures[i].height == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: zero-sized texture");
+            const uint8_t* d;
+            if ((r = upload(c, s->textures[i].rgba8, (size_t)s->textures[i].width * s->textures[i].height * 4, &d)) != HRPT_OK) return r;
+            table[i].rgba8 = d;
+        }
+    }
+    if ((r = upload(c, table.data(), table.size(), &v.textures)) != HRPT_OK) return r;
+    v.textureCount = s->textureCount;
+
+    // Bruneton LUTs: float32 file layout -> RGBA16F (src/CommonResources.cpp:534-558)
+    const size_t nT = 256u * 64u * 4u, nS = 256u * 128u * 32u * 4u;
+    std::vector<uint16_t> hT(nT), hS(nS);
+    for (size_t i = 0; i < nT; ++i) hT[i] = float_to_half(s->brunetonTransmittance[i]);
+    for (size_t i = 0; i < nS; ++i) hS[i] = float_to_half(s->brunetonScattering[i]);
+    if ((r = upload(c, hT.data(), nT, &v.lutTransmittance)) != HRPT_OK) return r;
+    if ((r = upload(c, hS.data(), nS, &v.lutScattering)) != HRPT_OK) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // host staging vectors die at scope exit
+
+    c->view = v; c->haveScene = true;
+    c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
+    return HRPT_OK;
+}
+
+int hrpt_resize(HrptContext* c, uint32_t width, uint32_t height)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (width == 0 || height == 0 || width > 65535u || height > 65535u)
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resize: size must be 1..65535 (RNG seed packs y*65536+x, RNG.hlsli:24)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dAccum) { (void)hipFree(c->dAccum); c->dAccum = nullptr; }
+    if (c->dOutput) { (void)hipFree(c->dOutput); c->dOutput = nullptr; }
+    size_t bytes = (size_t)width * height * sizeof(float4);
+    HIP_TRY(c, hipMalloc((void**)&c->dAccum, bytes));
+    HIP_TRY(c, hipMalloc((void**)&c->dOutput, bytes));
+    HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dOutput, 0, bytes, c->stream));
+    c->width = width; c->height = height;
+    return HRPT_OK;
+}
+
+float hrpt_halton(uint32_t index, uint32_t base)   // src/Utilities.cpp:67-79
+{
+    float result = 0.0f;
+    float f = 1.0f / (float)base;
+    uint32_t i = index;
+    while (i > 0) {
+        result += f * (float)(i % base);
+        i /= base;
+        f /= (float)base;
+    }
+    return result;
+}
+
+int hrpt_render(HrptContext* c, const HrptFrameParams* p)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!p) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: null params");
+    if (!c->haveScene) return fail(c, HRPT_ERR_NO_SCENE, "hrpt_render: no scene uploaded");
+    if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: hrpt_resize not called");
+    if (p->accumCount == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: accumCount == 0");
+    uint32_t vw = (uint32_t)p->constants.m_View.m_ViewportSize[0], vh = (uint32_t)p->constants.m_View.m_ViewportSize[1];
+    if (vw != c->width || vh != c->height) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_ViewportSize does not match hrpt_resize");
+    TileRect rect{ p->tileX0, p->tileY0, p->tileX1, p->tileY1 };
+    if (rect.x0 == 0 && rect.y0 == 0 && rect.x1 == 0 && rect.y1 == 0) { rect.x1 = c->width; rect.y1 = c->height; }
+    if (rect.x1 > c->width || rect.y1 > c->height || rect.x0 > rect.x1 || rect.y0 > rect.y1)
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: tile rectangle outside the image");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    bool wavefront = (p->flags & HRPT_FRAME_MEGAKERNEL) == 0 && wavefront_supports(c->view, p->constants);
+    c->traceMs = 0.0f; c->traceLaunches = 0;
+    HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+    if (wavefront) {
+        std::string werr;
+        hipError_t e = wavefront_render(c->wf, c->view, p->constants, p->accumCount, c->dAccum, c->dOutput, c->width, c->height, rect,
+                                        c->dCounters, c->stream, werr);
+        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? HRPT_ERR_OUT_OF_MEMORY : HRPT_ERR_HIP, "wavefront_render: " + werr + ": " + hipGetErrorString(e));
+    } else {
+        for (uint32_t k = 0; k < p->accumCount; ++k) {
+            HrptPathTracerConstants cb = p->constants;
+            cb.m_AccumulationIndex = p->constants.m_AccumulationIndex + k;                 // PathTracerRenderer.cpp:62,:105
+            cb.m_Jitter[0] = hrpt_halton(cb.m_AccumulationIndex + 1, 2) - 0.5f;            // :65
+            cb.m_Jitter[1] = hrpt_halton(cb.m_AccumulationIndex + 1, 3) - 0.5f;
+            HIP_TRY(c, launch_megakernel(c->view, cb, c->dAccum, c->dOutput, c->width, rect, c->dCounters, c->stream));
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+    c->timed = true;
+    return HRPT_OK;
+}
+
+int hrpt_synchronize(HrptContext* c)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HRPT_OK;
+}
+
+int hrpt_get_device_images(HrptContext* c, void** accumulation, void** output)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_device_images: hrpt_resize not called");
+    if (accumulation) *accumulation = c->dAccum;
+    if (output) *output = c->dOutput;
+    return HRPT_OK;
+}
+
+static int read_image(HrptContext* c, const float4* src, float* dst, size_t bytes, const char* what)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!dst || !src || bytes != (size_t)c->width * c->height * 16) return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string(what) + ": bad buffer size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HRPT_OK;
+}
+int hrpt_read_accumulation(HrptContext* c, float* rgba, size_t bytes) { return read_image(c, c ? c->dAccum : nullptr, rgba, bytes, "hrpt_read_accumulation"); }
+int hrpt_read_output(HrptContext* c, float* rgba, size_t bytes) { return read_image(c, c ? c->dOutput : nullptr, rgba, bytes, "hrpt_read_output"); }
+
+int hrpt_write_accumulation(HrptContext* c, const float* rgba, size_t bytes)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!rgba || !c->dAccum || bytes != (size_t)c->width * c->height * 16) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_write_accumulation: bad buffer size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->dAccum, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HRPT_OK;
+}
+
+int hrpt_resolve_output(HrptContext* c)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_output: hrpt_resize not called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_resolve(c->dAccum, c->dOutput, c->width * c->height, c->stream));
+    return HRPT_OK;
+}
+
+int hrpt_get_stats(HrptContext* c, HrptStats* out)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_stats: null out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DeviceCounters h{};
+    HIP_TRY(c, hipMemcpy(&h, c->dCounters, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->closestRays = h.closestRays; out->shadowRays = h.shadowRays; out->paths = h.paths;
+    if (c->timed) { float ms = 0.0f; if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess) out->lastRenderMs = ms; }
+    wavefront_trace_timing(c->wf, &out->traceKernelMs, &out->traceKernelLaunches);
+    out->bvhNodeCount = c->bvhNodes; out->bvhTriangleCount = c->bvhTris;
+    return HRPT_OK;
+}
+
+int hrpt_reset_stats(HrptContext* c)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
+    return HRPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,750 @@
+// pt_device.h -- gfx950 device code shared by the path-tracer kernels: vector algebra, BVH
+// traversal with a watertight triangle test, bindless/LUT sampling, Bruneton atmosphere
+// lookups, PBR BRDF evaluation and sampling.
+//
+// Follows /root/reference/src/shaders/{PathTracer.hlsl, RaytracingCommon.hlsli,
+// CommonLighting.hlsli, Atmosphere.hlsli, MeshCommon.hlsli, Common.hlsli, RNG.hlsli}; each
+// function names the lines it implements. Scalar HLSL intrinsics come from the numeric
+// contract include/hobbyrt/detmath.h; expression order is fixed (left to right, no FMA
+// contraction: build with -ffp-contract=off) so that radiance is a pure function of
+// (Scene, constants, pixel, accumulation index).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hobbyrt_pt.h"
+#include "../../include/hobbyrt/detmath.h"
+
+#define HRT_DEV __device__ __forceinline__
+
+namespace hrt {
+
+// ------------------------------------------------------------------ vectors
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+HRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+HRT_DEV f3 mk3(const float* p) { return mk3(p[0], p[1], p[2]); }
+HRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HRT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+HRT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+HRT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+HRT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+HRT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HRT_DEV float length(f3 a) { return hrt_sqrt(dot(a, a)); }
+HRT_DEV f3 normalize(f3 a) { float inv = 1.0f / hrt_sqrt(dot(a, a)); return a * inv; }
+HRT_DEV float lerp(float a, float b, float t) { return a + t * (b - a); }
+HRT_DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+HRT_DEV float maxcomp(f3 a) { return hrt_max(a.x, hrt_max(a.y, a.z)); }
+HRT_DEV f3 reflect(f3 i, f3 n) { float s = 2.0f * dot(i, n); return i - n * s; }
+HRT_DEV f3 refract(f3 i, f3 n, float eta)
+{
+    float d = dot(n, i);
+    float k = 1.0f - (eta * eta) * (1.0f - d * d);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float s = eta * d + hrt_sqrt(k);
+    return i * eta - n * s;
+}
+HRT_DEV f4 lerp4(f4 a, f4 b, float t)
+{
+    f4 r; float w = 1.0f - t;
+    r.x = a.x * w + b.x * t; r.y = a.y * w + b.y * t; r.z = a.z * w + b.z * t; r.w = a.w * w + b.w * t;
+    return r;
+}
+
+// ------------------------------------------------------------------ device scene view
+struct GpuNode {            // 64 B: both child boxes live in the parent -> one 64 B read per step
+    float lmin[3]; int32_t left;    // child >= 0: inner node index; child < 0: leaf = ~((first << 2) | (count - 1))
+    float lmax[3]; int32_t right;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+struct GpuTri {             // 48 B world-space triangle (instance transform applied at upload)
+    float p0[3]; uint32_t inst;
+    float p1[3]; uint32_t prim;
+    float p2[3]; uint32_t flags;    // bit 0: instance is ForceOpaque (src/Scene.cpp:150-154)
+};
+struct GpuTexture { const uint8_t* rgba8; uint32_t w, h; };
+
+struct SceneView {
+    const GpuNode* nodes; uint32_t nodeCount;
+    const GpuTri* tris; uint32_t triCount;
+    int32_t rootLeaf;       // when the whole scene fits one leaf: encoded leaf, else 0
+    const HrptVertexQuantized* vertices;
+    const uint32_t* indices; uint32_t indexCount;
+    const HrptMeshData* meshData;
+    const HrptPerInstanceData* instances;
+    const HrptMaterialConstants* materials;
+    const HrptGPULight* lights; uint32_t lightCount;
+    const GpuTexture* textures; uint32_t textureCount;
+    const uint16_t* lutTransmittance;   // 256 x 64 RGBA16F
+    const uint16_t* lutScattering;      // 256 x 128 x 32 RGBA16F
+};
+
+// ------------------------------------------------------------------ rays and hits
+struct Ray { f3 o, d; float tmin, tmax; };
+struct Hit { float t; uint32_t inst, prim; float u, v; uint32_t opaque; bool valid; };
+struct HitKey { float t; uint32_t inst, prim; bool have; };
+
+struct RayShear { int kx, ky, kz; float Sx, Sy, Sz; };
+
+HRT_DEV RayShear make_shear(f3 d)
+{
+    RayShear s;
+    int kz = 0;
+    if (hrt_abs(d.y) > hrt_abs(comp(d, kz))) kz = 1;
+    if (hrt_abs(d.z) > hrt_abs(comp(d, kz))) kz = 2;
+    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    if (comp(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
+    s.kx = kx; s.ky = ky; s.kz = kz;
+    float dz = comp(d, kz);
+    s.Sx = comp(d, kx) / dz; s.Sy = comp(d, ky) / dz; s.Sz = 1.0f / dz;
+    return s;
+}
+HRT_DEV bool key_less(float t, uint32_t inst, uint32_t prim, float t2, uint32_t inst2, uint32_t prim2)
+{
+    if (t < t2) return true;
+    if (t > t2) return false;
+    if (inst < inst2) return true;
+    if (inst > inst2) return false;
+    return prim < prim2;
+}
+// Watertight ray/triangle test (Woop, Benthin, Wald 2013) in fp32; no culling; (u,v) = DXR barycentrics.
+HRT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& r, const RayShear& s, float& t, float& u, float& v)
+{
+    f3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
+    float Akz = comp(A, s.kz), Bkz = comp(B, s.kz), Ckz = comp(C, s.kz);
+    float Ax = comp(A, s.kx) - s.Sx * Akz, Ay = comp(A, s.ky) - s.Sy * Akz;
+    float Bx = comp(B, s.kx) - s.Sx * Bkz, By = comp(B, s.ky) - s.Sy * Bkz;
+    float Cx = comp(C, s.kx) - s.Sx * Ckz, Cy = comp(C, s.ky) - s.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    float Az = s.Sz * Akz, Bz = s.Sz * Bkz, Cz = s.Sz * Ckz;
+    float T = (U * Az + V * Bz) + W * Cz;
+    float rcp = 1.0f / det;
+    float tt = T * rcp;
+    if (!(tt > r.tmin && tt < r.tmax)) return false;
+    t = tt; u = V * rcp; v = W * rcp;
+    return true;
+}
+
+// Node/triangle fetch policy: the BVH is read either from HBM/L2 (global) or from an LDS copy.
+struct GlobalBvh {
+    const GpuNode* nodes; const GpuTri* tris;
+    HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const
+    {
+        const float4* p = reinterpret_cast<const float4*>(nodes + i);
+        a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    }
+    HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
+    {
+        const float4* p = reinterpret_cast<const float4*>(tris + i);
+        a = p[0]; b = p[1]; c = p[2];
+    }
+};
+
+// Conservative slab test of one child box against [t0, t1]; returns entry distance or -1.
+HRT_DEV bool slab(const float* bmin, const float* bmax, const Ray& r, f3 inv, float t0, float t1, float& tnear)
+{
+    float lo0 = t0, hi0 = t1;
+    const float o[3] = { r.o.x, r.o.y, r.o.z };
+    const float d[3] = { r.d.x, r.d.y, r.d.z };
+    const float iv[3] = { inv.x, inv.y, inv.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (d[k] == 0.0f) {
+            if (o[k] < bmin[k] || o[k] > bmax[k]) return false;
+        } else {
+            float ta = (bmin[k] - o[k]) * iv[k], tb = (bmax[k] - o[k]) * iv[k];
+            float lo = hrt_min(ta, tb), hi = hrt_max(ta, tb);
+            lo = lo - hrt_abs(lo) * 1e-6f; hi = hi + hrt_abs(hi) * 1e-6f;
+            lo0 = hrt_max(lo0, lo); hi0 = hrt_min(hi0, hi);
+        }
+    }
+    tnear = lo0;
+    return lo0 <= hi0;
+}
+
+struct TravStats { uint32_t nodes, tris; };
+
+// Closest triangle (opaque or not) with key strictly above `lower` (when lower.have) in
+// (t, inst, prim) order. STACK: per-lane traversal stack accessor (LDS or private).
+template <class BVH, class STACK>
+HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack)
+{
+    Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0;
+    if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
+    RayShear sh = make_shear(r.d);
+    f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    int sp = 0;
+    int32_t cur;                       // current node reference: >= 0 inner, < 0 leaf
+    if (nodeCount == 0) { if (rootLeaf == 0) return best; cur = rootLeaf; }
+    else cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
+            float lmin[3] = { a.x, a.y, a.z }, lmax[3] = { b.x, b.y, b.z };
+            float rmin[3] = { c.x, c.y, c.z }, rmax[3] = { d.x, d.y, d.z };
+            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
+            float tl, tr;
+            float tlim = best.valid ? best.t : r.tmax;
+            bool hl = slab(lmin, lmax, r, inv, r.tmin, tlim, tl);
+            bool hr = slab(rmin, rmax, r, inv, r.tmin, tlim, tr);
+            if (hl && hr) {
+                bool leftFirst = tl <= tr;
+                int32_t nearI = leftFirst ? li : ri, farI = leftFirst ? ri : li;
+                stack.push(sp++, farI);
+                cur = nearI;
+                continue;
+            } else if (hl) { cur = li; continue; }
+            else if (hr) { cur = ri; continue; }
+        } else {
+            uint32_t enc = (uint32_t)(~cur);
+            uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                float4 a, b, c; bvh.tri(first + i, a, b, c);
+                float t, u, v;
+                if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), r, sh, t, u, v)) {
+                    uint32_t inst = __float_as_uint(a.w), prim = __float_as_uint(b.w);
+                    bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+                    if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
+                        best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
+                        best.opaque = __float_as_uint(c.w) & 1u;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack.pop(--sp);
+    }
+    return best;
+}
+
+// Any opaque-instance triangle in (tmin, tmax)? Early exit. Non-opaque triangles are ignored.
+template <class BVH, class STACK>
+HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, bool& sawNonOpaque)
+{
+    sawNonOpaque = false;
+    if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
+    RayShear sh = make_shear(r.d);
+    f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    int sp = 0; int32_t cur;
+    if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
+    else cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
+            float lmin[3] = { a.x, a.y, a.z }, lmax[3] = { b.x, b.y, b.z };
+            float rmin[3] = { c.x, c.y, c.z }, rmax[3] = { d.x, d.y, d.z };
+            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
+            float tl, tr;
+            bool hl = slab(lmin, lmax, r, inv, r.tmin, r.tmax, tl);
+            bool hr = slab(rmin, rmax, r, inv, r.tmin, r.tmax, tr);
+            if (hl && hr) { stack.push(sp++, ri); cur = li; continue; }
+            else if (hl) { cur = li; continue; }
+            else if (hr) { cur = ri; continue; }
+        } else {
+            uint32_t enc = (uint32_t)(~cur);
+            uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                float4 a, b, c; bvh.tri(first + i, a, b, c);
+                float t, u, v;
+                if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), r, sh, t, u, v)) {
+                    if (__float_as_uint(c.w) & 1u) return true;
+                    sawNonOpaque = true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack.pop(--sp);
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ vertex fetch
+struct Vtx { f3 pos, normal; f2 uv; f4 tangent; };
+
+// DecodeOct, Common.hlsli:174-181
+HRT_DEV f3 decode_oct(float ex, float ey)
+{
+    f3 v = mk3(ex, ey, (1.0f - hrt_abs(ex)) - hrt_abs(ey));
+    float t = hrt_max(-v.z, 0.0f);
+    v.x += (v.x >= 0.0f) ? -t : t;
+    v.y += (v.y >= 0.0f) ? -t : t;
+    return normalize(v);
+}
+// UnpackVertex, MeshCommon.hlsli:9-22
+HRT_DEV Vtx unpack_vertex(const HrptVertexQuantized& q, bool wantTangent)
+{
+    Vtx v;
+    v.pos = mk3(q.m_Pos);
+    v.normal.x = (float)(q.m_Normal & 1023u) / 511.0f - 1.0f;
+    v.normal.y = (float)((q.m_Normal >> 10) & 1023u) / 511.0f - 1.0f;
+    v.normal.z = (float)((q.m_Normal >> 20) & 1023u) / 511.0f - 1.0f;
+    if (wantTangent) {
+        float ox = (float)(q.m_Tangent & 255u) / 127.0f - 1.0f;
+        float oy = (float)((q.m_Tangent >> 8) & 255u) / 127.0f - 1.0f;
+        f3 tg = decode_oct(ox, oy);
+        v.tangent.x = tg.x; v.tangent.y = tg.y; v.tangent.z = tg.z;
+    } else { v.tangent.x = 0; v.tangent.y = 0; v.tangent.z = 0; }
+    v.tangent.w = (q.m_Normal & (1u << 30)) != 0 ? -1.0f : 1.0f;
+    v.uv.x = hrt_f16tof32(q.m_Uv & 0xFFFFu); v.uv.y = hrt_f16tof32(q.m_Uv >> 16);
+    return v;
+}
+// GetTriangleVertices, RaytracingCommon.hlsli:33-50 (out-of-range structured reads return 0 like D3D)
+HRT_DEV void get_triangle_vertices(const SceneView& s, uint32_t prim, uint32_t indexBase, Vtx tv[3], bool wantTangent)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t ii = indexBase + 3u * prim + (uint32_t)k;
+        uint32_t vi = (ii < s.indexCount) ? s.indices[ii] : 0u;
+        HrptVertexQuantized q = s.vertices[vi];
+        tv[k] = unpack_vertex(q, wantTangent);
+    }
+}
+// GetInterpolatedUV, RaytracingCommon.hlsli:79-89
+HRT_DEV f2 interpolated_uv(const Vtx tv[3], float bx, float by)
+{
+    float w0 = (1.0f - bx) - by; f2 r;
+    r.x = (tv[0].uv.x * w0 + tv[1].uv.x * bx) + tv[2].uv.x * by;
+    r.y = (tv[0].uv.y * w0 + tv[1].uv.y * bx) + tv[2].uv.y * by;
+    return r;
+}
+// TransformNormal, Common.hlsli:33-47
+HRT_DEV f3 transform_normal(f3 n, const float* M)
+{
+    f3 r0 = mk3(M[0], M[1], M[2]), r1 = mk3(M[4], M[5], M[6]), r2 = mk3(M[8], M[9], M[10]);
+    f3 a0 = cross(r1, r2), a1 = cross(r2, r0), a2 = cross(r0, r1);
+    f3 o = mk3((n.x * a0.x + n.y * a1.x) + n.z * a2.x,
+               (n.x * a0.y + n.y * a1.y) + n.z * a2.y,
+               (n.x * a0.z + n.y * a1.z) + n.z * a2.z);
+    return normalize(o);
+}
+
+// ------------------------------------------------------------------ textures / LUTs
+HRT_DEV int wrap_i(int i, int n, bool wrap)
+{
+    if (wrap) { int m = i % n; return m < 0 ? m + n : m; }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+HRT_DEV f4 texel8(const GpuTexture& t, int x, int y)
+{
+    uint32_t p = reinterpret_cast<const uint32_t*>(t.rgba8)[(size_t)y * t.w + (size_t)x];
+    f4 r;
+    r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f;
+    r.z = (float)((p >> 16) & 255u) / 255.0f; r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+// SampleBindlessTextureLevel(lod 0), Bindless.hlsli:118-123, on an RGBA8_UNORM single-mip texture with
+// exact fp32 bilinear weights. Sampler table src/CommonResources.cpp:117-128.
+HRT_DEV f4 sample_texture(const SceneView& s, uint32_t texIndex, uint32_t samplerIndex, f2 uv)
+{
+    f4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
+    if (texIndex >= s.textureCount) return zero;
+    GpuTexture t = s.textures[texIndex];
+    if (!t.rgba8) return zero;
+    bool wrap = (samplerIndex <= 5u) ? ((samplerIndex & 1u) != 0) : false;
+    bool point = (samplerIndex == 2u || samplerIndex == 3u);
+    float fx = uv.x * (float)t.w, fy = uv.y * (float)t.h;
+    if (point) return texel8(t, wrap_i((int)hrt_floor(fx), (int)t.w, wrap), wrap_i((int)hrt_floor(fy), (int)t.h, wrap));
+    fx = fx - 0.5f; fy = fy - 0.5f;
+    float ix = hrt_floor(fx), iy = hrt_floor(fy);
+    float tx = fx - ix, ty = fy - iy;
+    int x0 = wrap_i((int)ix, (int)t.w, wrap), x1 = wrap_i((int)ix + 1, (int)t.w, wrap);
+    int y0 = wrap_i((int)iy, (int)t.h, wrap), y1 = wrap_i((int)iy + 1, (int)t.h, wrap);
+    f4 a = lerp4(texel8(t, x0, y0), texel8(t, x1, y0), tx);
+    f4 b = lerp4(texel8(t, x0, y1), texel8(t, x1, y1), tx);
+    return lerp4(a, b, ty);
+}
+HRT_DEV f4 lut_texel(const uint16_t* lut, size_t idx)
+{
+    uint2 p = reinterpret_cast<const uint2*>(lut)[idx];   // 4 halfs = 8 B, one coalescable load
+    f4 r;
+    r.x = hrt_f16tof32(p.x & 0xffffu); r.y = hrt_f16tof32(p.x >> 16);
+    r.z = hrt_f16tof32(p.y & 0xffffu); r.w = hrt_f16tof32(p.y >> 16);
+    return r;
+}
+HRT_DEV int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+HRT_DEV f4 sample_lut2d(const uint16_t* lut, int W, int H, float u, float v)
+{
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float ix = hrt_floor(fx), iy = hrt_floor(fy);
+    float tx = fx - ix, ty = fy - iy;
+    int x0 = clampi((int)ix, W), x1 = clampi((int)ix + 1, W), y0 = clampi((int)iy, H), y1 = clampi((int)iy + 1, H);
+    f4 a = lerp4(lut_texel(lut, (size_t)y0 * W + x0), lut_texel(lut, (size_t)y0 * W + x1), tx);
+    f4 b = lerp4(lut_texel(lut, (size_t)y1 * W + x0), lut_texel(lut, (size_t)y1 * W + x1), tx);
+    return lerp4(a, b, ty);
+}
+HRT_DEV f4 sample_lut3d(const uint16_t* lut, int W, int H, int D, float u, float v, float w)
+{
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f, fz = w * (float)D - 0.5f;
+    float ix = hrt_floor(fx), iy = hrt_floor(fy), iz = hrt_floor(fz);
+    float tx = fx - ix, ty = fy - iy, tz = fz - iz;
+    int x0 = clampi((int)ix, W), x1 = clampi((int)ix + 1, W), y0 = clampi((int)iy, H), y1 = clampi((int)iy + 1, H);
+    int z0 = clampi((int)iz, D), z1 = clampi((int)iz + 1, D);
+    size_t zo0 = (size_t)z0 * W * H, zo1 = (size_t)z1 * W * H;
+    f4 a0 = lerp4(lut_texel(lut, zo0 + (size_t)y0 * W + x0), lut_texel(lut, zo0 + (size_t)y0 * W + x1), tx);
+    f4 b0 = lerp4(lut_texel(lut, zo0 + (size_t)y1 * W + x0), lut_texel(lut, zo0 + (size_t)y1 * W + x1), tx);
+    f4 s0 = lerp4(a0, b0, ty);
+    f4 a1 = lerp4(lut_texel(lut, zo1 + (size_t)y0 * W + x0), lut_texel(lut, zo1 + (size_t)y0 * W + x1), tx);
+    f4 b1 = lerp4(lut_texel(lut, zo1 + (size_t)y1 * W + x0), lut_texel(lut, zo1 + (size_t)y1 * W + x1), tx);
+    f4 s1 = lerp4(a1, b1, ty);
+    return lerp4(s0, s1, tz);
+}
+
+// ------------------------------------------------------------------ atmosphere (Atmosphere.hlsli)
+namespace atm {
+constexpr float kBottom = 6360.0f, kTop = 6420.0f;
+constexpr float kSunAngularRadius = 0.004675f;      // 0.00935 / 2.0, Atmosphere.hlsli:42
+constexpr float kMuSMin = -0.207912f, kMieG = 0.8f;
+
+HRT_DEV f3 solar_irradiance() { return mk3(1.474000f, 1.850400f, 1.911980f); }
+HRT_DEV float safe_sqrt(float a) { return hrt_sqrt(hrt_max(a, 0.0f)); }
+HRT_DEV float dist_top(float r, float mu)                                   // :130-134
+{
+    float disc = r * r * (mu * mu - 1.0f) + kTop * kTop;
+    return hrt_max(-r * mu + safe_sqrt(disc), 0.0f);
+}
+HRT_DEV bool ray_hits_ground(float r, float mu)                              // :157-160
+{
+    return mu < 0.0f && r * r * (mu * mu - 1.0f) + kBottom * kBottom >= 0.0f;
+}
+HRT_DEV float texcoord(float x, int size) { return 0.5f / (float)size + x * (1.0f - 1.0f / (float)size); }   // :176-179
+HRT_DEV f3 transmittance_to_top(const SceneView& s, float r, float mu)      // :190-198, :207-211
+{
+    float rho = safe_sqrt(r * r - kBottom * kBottom);
+    float d = dist_top(r, mu);
+    float H = safe_sqrt(kTop * kTop - kBottom * kBottom);
+    float x_mu = texcoord(d / (rho + H), 256);
+    float x_r = texcoord(rho / H, 64);
+    f4 t = sample_lut2d(s.lutTransmittance, 256, 64, x_mu, x_r);
+    return mk3(t.x, t.y, t.z);
+}
+HRT_DEV f4 scattering_uvwz(float r, float mu, float mu_s, float nu, bool hitsGround)   // :263-297
+{
+    float H = hrt_sqrt(kTop * kTop - kBottom * kBottom);
+    float rho = safe_sqrt(r * r - kBottom * kBottom);
+    float u_r = texcoord(rho / H, 32);
+    float r_mu = r * mu;
+    float disc = r_mu * r_mu - r * r + kBottom * kBottom;
+    float u_mu;
+    if (hitsGround) {
+        float d = -r_mu - safe_sqrt(disc);
+        float d_min = r - kBottom, d_max = rho;
+        u_mu = 0.5f - 0.5f * texcoord(d_max == d_min ? 0.0f : (d - d_min) / (d_max - d_min), 64);
+    } else {
+        float d = -r_mu + safe_sqrt(disc + H * H);
+        float d_min = kTop - r, d_max = rho + H;
+        u_mu = 0.5f + 0.5f * texcoord((d - d_min) / (d_max - d_min), 64);
+    }
+    float d = dist_top(kBottom, mu_s);
+    float d_min = kTop - kBottom, d_max = H;
+    float a = (d - d_min) / (d_max - d_min);
+    float D = dist_top(kBottom, kMuSMin);
+    float A = (D - d_min) / (d_max - d_min);
+    float u_mu_s = texcoord(hrt_max(1.0f - a / A, 0.0f) / (1.0f + a), 32);
+    f4 o; o.x = (nu + 1.0f) / 2.0f; o.y = u_mu_s; o.z = u_mu; o.w = u_r;
+    return o;
+}
+HRT_DEV f3 combined_scattering(const SceneView& s, float r, float mu, float mu_s, float nu, bool hitsGround, f3& singleMie)  // :305-341
+{
+    f4 uvwz = scattering_uvwz(r, mu, mu_s, nu, hitsGround);
+    float tex_coord_x = uvwz.x * 7.0f;
+    float tex_x = hrt_floor(tex_coord_x);
+    float lerp_val = tex_coord_x - tex_x;
+    float u0 = (tex_x + uvwz.y) / 8.0f, u1 = (tex_x + 1.0f + uvwz.y) / 8.0f;
+    f4 s0 = sample_lut3d(s.lutScattering, 256, 128, 32, u0, uvwz.z, uvwz.w);
+    f4 s1 = sample_lut3d(s.lutScattering, 256, 128, 32, u1, uvwz.z, uvwz.w);
+    f4 cs = lerp4(s0, s1, lerp_val);
+    if (cs.x <= 0.0f) singleMie = mk3(0.0f, 0.0f, 0.0f);
+    else {
+        const f3 ray = mk3(0.005802f, 0.013558f, 0.033100f), mie = mk3(0.003996f, 0.003996f, 0.003996f);
+        float k = ray.x / mie.x;
+        f3 ratio = mk3(mie.x / ray.x, mie.y / ray.y, mie.z / ray.z);
+        f3 t = mk3(cs.x * cs.w / cs.x * k, cs.y * cs.w / cs.x * k, cs.z * cs.w / cs.x * k);
+        singleMie = t * ratio;
+    }
+    return mk3(cs.x, cs.y, cs.z);
+}
+HRT_DEV float rayleigh_phase(float nu) { float k = 3.0f / (16.0f * HRT_PI); return k * (1.0f + nu * nu); }   // :349-353
+HRT_DEV float mie_phase(float g, float nu)                                                                   // :355-359
+{
+    float k = 3.0f / (8.0f * HRT_PI) * (1.0f - g * g) / (2.0f + g * g);
+    float b = hrt_max(1.0f + g * g - 2.0f * g * nu, 0.0001f);
+    return k * (1.0f + nu * nu) / (b * hrt_sqrt(b));
+}
+HRT_DEV float smoothstep(float a, float b, float x) { float t = hrt_saturate((x - a) / (b - a)); return (t * t) * (3.0f - 2.0f * t); }
+HRT_DEV f3 transmittance_to_sun(const SceneView& s, float r, float mu_s)    // :414-420
+{
+    float sin_theta_h = kBottom / r;
+    float cos_theta_h = -hrt_sqrt(hrt_max(1.0f - sin_theta_h * sin_theta_h, 0.0f));
+    float e = sin_theta_h * kSunAngularRadius;
+    float f = smoothstep(-e, e, mu_s - cos_theta_h);
+    return transmittance_to_top(s, r, mu_s) * f;
+}
+HRT_DEV f3 atmosphere_pos(f3 worldPos) { return (worldPos - mk3(0.0f, -6360000.0f, 0.0f)) / 1000.0f; }   // :564-567
+HRT_DEV f3 sun_radiance(const SceneView& s, f3 p_atmo, f3 sunDir, float sunIntensity)   // :569-574
+{
+    float r = length(p_atmo);
+    float mu_s = dot(p_atmo, sunDir) / r;
+    return (solar_irradiance() * transmittance_to_sun(s, r, mu_s)) * sunIntensity;
+}
+// GetAtmosphereSkyRadiance :583-601 (GetSkyRadiance :458-500 with shadow_length 0)
+HRT_DEV f3 sky_radiance(const SceneView& s, f3 cameraPos, f3 viewRay, f3 sunDir, float sunIntensity, bool addSunDisk)
+{
+    f3 camera = atmosphere_pos(cameraPos);
+    float r = length(camera);
+    float rmu = dot(camera, viewRay);
+    float dtop = -rmu - safe_sqrt(rmu * rmu - r * r + kTop * kTop);
+    f3 transmittance, sky;
+    bool outside = false;
+    if (dtop > 0.0f) { camera = camera + viewRay * dtop; r = kTop; rmu += dtop; }
+    else if (r > kTop) outside = true;
+    if (outside) { transmittance = mk3(1.0f, 1.0f, 1.0f); sky = mk3(0.0f, 0.0f, 0.0f); }
+    else {
+        float mu = rmu / r;
+        float mu_s = dot(camera, sunDir) / r;
+        float nu = dot(viewRay, sunDir);
+        bool hitsGround = ray_hits_ground(r, mu);
+        transmittance = hitsGround ? mk3(0.0f, 0.0f, 0.0f) : transmittance_to_top(s, r, mu);
+        f3 mie;
+        f3 scat = combined_scattering(s, r, mu, mu_s, nu, hitsGround, mie);
+        sky = scat * rayleigh_phase(nu) + mie * mie_phase(kMieG, nu);
+    }
+    if (addSunDisk) {
+        float nu = dot(viewRay, sunDir);
+        if (nu > hrt_cos(kSunAngularRadius)) {
+            float den = HRT_PI * kSunAngularRadius * kSunAngularRadius;
+            f3 si = solar_irradiance();
+            sky = sky + mk3(si.x / den, si.y / den, si.z / den) * transmittance;
+        }
+    }
+    return sky * sunIntensity;
+}
+} // namespace atm
+
+// ------------------------------------------------------------------ BRDF (CommonLighting.hlsli)
+struct Lighting {            // the part of LightingInputs the path tracer reads
+    f3 N, V, L, baseColor; float roughness, metallic, ior;
+    f3 F0, F; float kD;
+    float NdotV, NdotL, NdotH, VdotH, LdotV, LdotH;
+};
+HRT_DEV f3 f_schlick(f3 spec, float VdotH)                                   // :123-129
+{
+    float Fc = hrt_pow5(1.0f - VdotH);
+    float s = hrt_saturate(50.0f * spec.y) * Fc;
+    float k = 1.0f - Fc;
+    return mk3(s + k * spec.x, s + k * spec.y, s + k * spec.z);
+}
+HRT_DEV f3 compute_f0(f3 baseColor, float metallic, float ior)               // :64-68
+{
+    float q = (ior - 1.0f) / (ior + 1.0f);
+    float d = q * q;
+    return mk3(lerp(d, baseColor.x, metallic), lerp(d, baseColor.y, metallic), lerp(d, baseColor.z, metallic));
+}
+HRT_DEV void prepare_byproducts(Lighting& in)                                // :316-334
+{
+    in.NdotV = hrt_saturate(dot(in.N, in.V));
+    in.NdotL = hrt_saturate(dot(in.N, in.L));
+    f3 VpL = in.V + in.L;
+    float len = dot(VpL, VpL);
+    f3 H = (len > 1e-8f) ? VpL * hrt_rsqrt(len) : in.N;
+    in.NdotH = hrt_saturate(dot(in.N, H));
+    in.VdotH = hrt_saturate(dot(in.V, H));
+    in.LdotV = hrt_saturate(dot(in.L, in.V));
+    in.LdotH = hrt_saturate(dot(in.L, H));
+    in.F0 = compute_f0(in.baseColor, in.metallic, in.ior);
+    in.kD = 1.0f - in.metallic;
+    in.F = f_schlick(in.F0, in.VdotH);
+}
+HRT_DEV float d_ggx(float NdotH, float roughness)                            // :80-86
+{
+    float alpha = roughness * roughness, alpha2 = alpha * alpha;
+    float denom = NdotH * NdotH * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (HRT_PI * denom * denom);
+}
+HRT_DEV float burley_diffuse(float NdotL, float NdotV, float LdotH, float rough)   // :148-168
+{
+    if (NdotL <= 0.0f || NdotV <= 0.0f) return 0.0f;
+    float rough2 = rough * rough;
+    float FL = hrt_pow5(1.0f - NdotL), FV = hrt_pow5(1.0f - NdotV);
+    float Fd90 = 0.5f + 2.0f * rough2 * LdotH * LdotH;
+    float Fd = lerp(1.0f, Fd90, FL) * lerp(1.0f, Fd90, FV);
+    return Fd * NdotL / HRT_PI;
+}
+// EvaluateDirectLight :360-375 with ComputeSpecularBRDF :345-358, before the shadow factor:
+// diffuse = (diffuseTerm*kD*baseColor)*radiance, specular = (spec*NdotL)*radiance.
+HRT_DEV void evaluate_direct_unshadowed(const Lighting& in, f3 radiance, f3& diffuse, f3& specular)
+{
+    float dt = burley_diffuse(in.NdotL, in.NdotV, in.LdotH, in.roughness);
+    f3 kd = mk3(in.kD, in.kD, in.kD);
+    f3 dif = (kd * dt) * in.baseColor;
+    float alpha = in.roughness * in.roughness, alpha2 = alpha * alpha;
+    float D = d_ggx(in.NdotH, in.roughness);
+    float g1 = in.NdotV * hrt_sqrt(alpha2 + (1.0f - alpha2) * in.NdotL * in.NdotL);
+    float g2 = in.NdotL * hrt_sqrt(alpha2 + (1.0f - alpha2) * in.NdotV * in.NdotV);
+    float G2 = 0.5f / hrt_max(g1 + g2, 1e-6f);
+    float k = D * G2;
+    f3 spec = in.F * k;
+    diffuse = dif * radiance;
+    specular = (spec * in.NdotL) * radiance;
+}
+HRT_DEV void tangent_frame(f3 N, f3& T, f3& B)                                // :610-615, :176-178, :702-704
+{
+    f3 up = hrt_abs(N.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+    T = normalize(cross(up, N));
+    B = cross(N, T);
+}
+HRT_DEV f3 frame_combine(f3 T, f3 N, f3 B, f3 l) { return (T * l.x + N * l.y) + B * l.z; }
+HRT_DEV f3 sample_hemisphere_cosine(float ux, float uy, f3 normal)            // :170-183
+{
+    float phi = 2.0f * HRT_PI * ux;
+    float cosTheta = hrt_sqrt(uy);
+    float sinTheta = hrt_sqrt(hrt_max(0.0f, 1.0f - cosTheta * cosTheta));
+    float sp, cp; hrt_sincos(phi, &sp, &cp);
+    f3 T, B; tangent_frame(normal, T, B);
+    return frame_combine(T, normal, B, mk3(sinTheta * cp, cosTheta, sinTheta * sp));
+}
+HRT_DEV f3 sample_ggx_vndf(float ux, float uy, f3 N, f3 V, float roughness)   // :622-655
+{
+    float alpha = roughness * roughness;
+    f3 T, B; tangent_frame(N, T, B);
+    f3 Vl = mk3(dot(V, T), dot(V, N), dot(V, B));
+    f3 Vh = normalize(mk3(alpha * Vl.x, Vl.y, alpha * Vl.z));
+    float lensq = Vh.x * Vh.x + Vh.z * Vh.z;
+    f3 T1 = lensq > 0.0f ? mk3(-Vh.z, 0.0f, Vh.x) / hrt_sqrt(lensq) : mk3(1.0f, 0.0f, 0.0f);
+    f3 T2 = cross(Vh, T1);
+    float r = hrt_sqrt(ux);
+    float phi = 2.0f * HRT_PI * uy;
+    float sp, cp; hrt_sincos(phi, &sp, &cp);
+    float t1 = r * cp, t2 = r * sp;
+    float s = 0.5f * (1.0f + Vh.y);
+    t2 = lerp(hrt_sqrt(hrt_max(0.0f, 1.0f - t1 * t1)), t2, s);
+    float nz = hrt_sqrt(hrt_max(0.0f, (1.0f - t1 * t1) - t2 * t2));
+    f3 Nh = (T1 * t1 + T2 * t2) + Vh * nz;
+    f3 Ne = normalize(mk3(alpha * Nh.x, hrt_max(0.0f, Nh.y), alpha * Nh.z));
+    return frame_combine(T, N, B, Ne);
+}
+HRT_DEV f3 eval_ggx_vndf_weight(f3 F0, f3 N, f3 V, f3 L, f3 H, float roughness)   // :671-688
+{
+    float alpha = roughness * roughness, alpha2 = alpha * alpha;
+    float NdotV = hrt_saturate(dot(N, V)), NdotL = hrt_saturate(dot(N, L)), VdotH = hrt_saturate(dot(V, H));
+    if (NdotV <= 0.0f || NdotL <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    f3 F = f_schlick(F0, VdotH);
+    float G1L = 2.0f * NdotL / (NdotL + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL * NdotL));
+    return F * G1L;
+}
+HRT_DEV f3 sample_cone(f3 dir, float cosHalf, float ux, float uy)             // :693-708
+{
+    float cosTheta = 1.0f - ux * (1.0f - cosHalf);
+    float sinTheta = hrt_sqrt(hrt_max(0.0f, 1.0f - cosTheta * cosTheta));
+    float phi = 2.0f * HRT_PI * uy;
+    float sp, cp; hrt_sincos(phi, &sp, &cp);
+    f3 T, B; tangent_frame(dir, T, B);
+    return frame_combine(T, dir, B, mk3(sinTheta * cp, cosTheta, sinTheta * sp));
+}
+// EvalFresnelDielectric, PathTracer.hlsl:26-43
+HRT_DEV float fresnel_dielectric(float eta, float cosThetaI, float& cosThetaT)
+{
+    if (cosThetaI < 0.0f) { eta = 1.0f / eta; cosThetaI = -cosThetaI; }
+    float sinThetaTSq = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaTSq >= 1.0f) { cosThetaT = 0.0f; return 1.0f; }
+    cosThetaT = hrt_sqrt(hrt_max(0.0f, 1.0f - sinThetaTSq));
+    float Rs = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    float Rp = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+// candidate alpha = mat.m_BaseColor.w [* albedo.a] (RaytracingCommon.hlsli:97-103, :172-176)
+HRT_DEV float candidate_alpha(const SceneView& s, const HrptMaterialConstants& mat, f2 uv)
+{
+    float alpha = mat.m_BaseColor[3];
+    if (mat.m_TextureFlags & HRPT_TEXFLAG_ALBEDO) alpha *= sample_texture(s, mat.m_AlbedoTextureIndex, mat.m_AlbedoSamplerIndex, uv).w;
+    return alpha;
+}
+
+struct SurfaceAttr { f3 worldPos, worldNormal, worldTangent; float tangentSign; f2 uv; };
+struct Pbr { f3 baseColor; float alpha, roughness, metallic; f3 emissive, normal; };
+
+// GetFullHitAttributes, RaytracingCommon.hlsli:52-77 (LOD 0: PathTracer.hlsl:103)
+HRT_DEV SurfaceAttr full_hit_attributes(const SceneView& s, const Hit& hit, const Ray& ray, const HrptPerInstanceData& inst,
+                                        uint32_t indexBase, bool wantTangent)
+{
+    Vtx tv[3]; get_triangle_vertices(s, hit.prim, indexBase, tv, wantTangent);
+    float bx = (1.0f - hit.u) - hit.v, by = hit.u, bz = hit.v;
+    SurfaceAttr a;
+    a.worldPos = ray.o + ray.d * hit.t;
+    f3 ln = (tv[0].normal * bx + tv[1].normal * by) + tv[2].normal * bz;
+    a.worldNormal = transform_normal(ln, inst.m_World);
+    if (wantTangent) {
+        f3 t0 = mk3(tv[0].tangent.x, tv[0].tangent.y, tv[0].tangent.z), t1 = mk3(tv[1].tangent.x, tv[1].tangent.y, tv[1].tangent.z),
+           t2 = mk3(tv[2].tangent.x, tv[2].tangent.y, tv[2].tangent.z);
+        f3 lt = (t0 * bx + t1 * by) + t2 * bz;
+        a.worldTangent = transform_normal(lt, inst.m_World);
+    } else a.worldTangent = mk3(0.0f, 0.0f, 0.0f);
+    a.tangentSign = (tv[0].tangent.w * bx + tv[1].tangent.w * by) + tv[2].tangent.w * bz;
+    a.uv.x = (tv[0].uv.x * bx + tv[1].uv.x * by) + tv[2].uv.x * bz;
+    a.uv.y = (tv[0].uv.y * bx + tv[1].uv.y * by) + tv[2].uv.y * bz;
+    return a;
+}
+// TransformNormalWithTBN, Common.hlsli:183-200
+HRT_DEV f3 normal_with_tbn(float nx, float ny, f3 normal, f3 tangent, float tangentSign)
+{
+    float x = 2.0f * nx - 1.0f, y = 2.0f * ny - 1.0f;
+    float z = hrt_sqrt(hrt_saturate(1.0f - (x * x + y * y)));
+    f3 n_w = normalize(normal);
+    f3 t_w = normalize(tangent);
+    t_w = normalize(t_w - n_w * dot(t_w, n_w));
+    f3 b_w = normalize(cross(n_w, t_w) * tangentSign);
+    f3 o = mk3((x * t_w.x + y * b_w.x) + z * n_w.x, (x * t_w.y + y * b_w.y) + z * n_w.y, (x * t_w.z + y * b_w.z) + z * n_w.z);
+    return normalize(o);
+}
+// GetPBRAttributes, RaytracingCommon.hlsli:252-296
+HRT_DEV Pbr pbr_attributes(const SceneView& s, const SurfaceAttr& a, const HrptMaterialConstants& m)
+{
+    Pbr p;
+    p.baseColor = mk3(m.m_BaseColor); p.alpha = m.m_BaseColor[3];
+    if (m.m_TextureFlags & HRPT_TEXFLAG_ALBEDO) {
+        f4 t = sample_texture(s, m.m_AlbedoTextureIndex, m.m_AlbedoSamplerIndex, a.uv);
+        p.baseColor = p.baseColor * mk3(t.x, t.y, t.z); p.alpha *= t.w;
+    }
+    p.roughness = m.m_RoughnessMetallic[0];
+    p.metallic = m.m_RoughnessMetallic[1];
+    if (m.m_TextureFlags & HRPT_TEXFLAG_ROUGHNESS_METALLIC) {
+        f4 t = sample_texture(s, m.m_RoughnessMetallicTextureIndex, m.m_RoughnessSamplerIndex, a.uv);
+        p.roughness = t.y; p.metallic = t.z;
+    }
+    p.roughness = hrt_max(p.roughness, 0.04f);
+    p.emissive = mk3(m.m_EmissiveFactor);
+    if (m.m_TextureFlags & HRPT_TEXFLAG_EMISSIVE) {
+        f4 t = sample_texture(s, m.m_EmissiveTextureIndex, m.m_EmissiveSamplerIndex, a.uv);
+        p.emissive = p.emissive * mk3(t.x, t.y, t.z);
+    }
+    if (m.m_TextureFlags & HRPT_TEXFLAG_NORMAL) {
+        f4 t = sample_texture(s, m.m_NormalTextureIndex, m.m_NormalSamplerIndex, a.uv);
+        p.normal = normal_with_tbn(t.x, t.y, a.worldNormal, a.worldTangent, a.tangentSign);
+    } else p.normal = normalize(a.worldNormal);
+    return p;
+}
+
+// Light distance attenuation, CommonLighting.hlsli:766-769 / :835-837 (pow(x,4), pow(x,2) by multiplication)
+HRT_DEV float distance_attenuation(const HrptGPULight& l, float distSq, float dist)
+{
+    float a = 1.0f / (distSq + 1.0f);
+    if (l.m_Range > 0.0f) {
+        float q = dist / l.m_Range; float q2 = q * q; float q4 = q2 * q2;
+        float sa = hrt_saturate(1.0f - q4);
+        a *= sa * sa;
+    }
+    return a;
+}
+
+} // namespace hrt

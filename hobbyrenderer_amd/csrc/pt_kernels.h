@@ -1,0 +1,30 @@
+// pt_kernels.h -- host-callable launchers of the gfx950 path-tracer kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hobbyrt_pt.h"
+
+namespace hrt {
+
+struct SceneView;   // pt_device.h
+
+struct DeviceCounters {         // one instance in device memory per context
+    unsigned long long closestRays;
+    unsigned long long shadowRays;
+    unsigned long long paths;
+    unsigned long long pad;
+};
+
+struct TileRect { uint32_t x0, y0, x1, y1; };
+
+// One dispatch of the reference shader: one path per pixel of `rect` for constants.m_AccumulationIndex.
+// Validation path: one thread per pixel, private traversal stack.
+hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation,
+                             float4* output, uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream);
+
+// Output[xy] = accum.rgb / accum.a (PathTracer.hlsl:339) over the whole image.
+hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream);
+
+} // namespace hrt

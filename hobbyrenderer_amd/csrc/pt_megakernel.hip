@@ -1,0 +1,109 @@
+// pt_megakernel.hip -- validation kernel: one thread per pixel runs the whole of PathTracer_CSMain
+// (/root/reference/src/shaders/PathTracer.hlsl:53-340) for one accumulation index, exactly like one
+// dispatch of the reference (8x8 groups -> here 64-lane waves over 8x8 pixel tiles). It exists to prove
+// struct layouts, RNG streams, LUT sampling, the BVH and the shading stages bit-for-bit against the CPU
+// oracle; the wavefront pipeline (pt_wavefront.hip) is the production path and reuses the same stages.
+#include "pt_kernels.h"
+#include "pt_path.h"
+
+namespace hrt {
+
+struct PrivateStack {
+    int32_t e[32];
+    HRT_DEV void push(int sp, int32_t v) { e[sp & 31] = v; }
+    HRT_DEV int32_t pop(int sp) { return e[sp & 31]; }
+};
+
+HRT_DEV unsigned long long wave_sum(unsigned int v)
+{
+    unsigned long long x = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerConstants cb, float4* __restrict__ accumulation,
+                                                    float4* __restrict__ output, uint32_t imageWidth, TileRect rect,
+                                                    DeviceCounters* counters)
+{
+    // 8x8 pixel tile per 64-lane wave (same footprint as [numthreads(8,8,1)], PathTracer.hlsl:52)
+    uint32_t lx = threadIdx.x & 7u, ly = threadIdx.x >> 3;
+    uint32_t px = rect.x0 + blockIdx.x * 8u + lx, py = rect.y0 + blockIdx.y * 8u + ly;
+    bool active = px < rect.x1 && py < rect.y1;
+    unsigned int nClosest = 0, nShadow = 0;
+
+    if (active) {
+        GlobalBvh bvh; bvh.nodes = s.nodes; bvh.tris = s.tris;
+        PrivateStack stack;
+        PathState ps; init_path(ps, cb, px, py);
+        int maxBounces = (int)cb.m_MaxBounces;
+        for (int bounce = 0; bounce < maxBounces; ++bounce) {
+            Hit hit;
+            ++nClosest;
+            if (trace_standard(s, bvh, ps.ray, ps.rng, stack, hit)) {
+                SurfaceCarry carry;
+                f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
+                f3 neeThroughput;
+                SurfaceOutcome oc = shade_surface_a(s, cb, ps, hit, carry, [&](uint32_t, f3 worldPos, f3 L, float maxDist, f3 dif, f3 spec) {
+                    ++nShadow;
+                    float shadow = shadow_query(s, bvh, worldPos, L, maxDist, stack);
+                    totalDiffuse = totalDiffuse + dif * shadow;
+                    totalSpecular = totalSpecular + spec * shadow;
+                });
+                if (oc == SURFACE_TRANSMITTED) continue;
+                neeThroughput = ps.throughput;
+                f3 dsum = totalDiffuse + (bounce == 0 ? totalSpecular : mk3(0.0f, 0.0f, 0.0f));
+                ps.radiance = ps.radiance + neeThroughput * dsum;                   // PathTracer.hlsl:261
+                if (!shade_surface_b(ps, carry, bounce)) break;
+            } else {
+                miss_sky(s, cb, ps, bounce);
+                break;
+            }
+        }
+        // accumulate + resolve, PathTracer.hlsl:332-339
+        size_t idx = (size_t)py * imageWidth + px;
+        float4 accum = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 1.0f);
+        if (cb.m_AccumulationIndex > 0) {
+            float4 prev = accumulation[idx];
+            accum.x += prev.x; accum.y += prev.y; accum.z += prev.z; accum.w += prev.w;
+        }
+        accumulation[idx] = accum;
+        output[idx] = make_float4(accum.x / accum.w, accum.y / accum.w, accum.z / accum.w, 1.0f);
+    }
+    unsigned long long c = wave_sum(nClosest), sh = wave_sum(nShadow), pa = wave_sum(active ? 1u : 0u);
+    if (threadIdx.x == 0) {
+        atomicAdd(&counters->closestRays, c);
+        atomicAdd(&counters->shadowRays, sh);
+        atomicAdd(&counters->paths, pa);
+    }
+}
+
+__global__ void pt_resolve_kernel(const float4* __restrict__ accumulation, float4* __restrict__ output, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 a = accumulation[i];
+        output[i] = make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f);
+    }
+}
+
+hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation, float4* output,
+                             uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream)
+{
+    if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0) return hipSuccess;
+    dim3 grid((rect.x1 - rect.x0 + 7) / 8, (rect.y1 - rect.y0 + 7) / 8, 1);
+    hipLaunchKernelGGL(pt_megakernel, grid, dim3(64, 1, 1), 0, stream, scene, constants, accumulation, output, imageWidth, rect, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream)
+{
+    if (pixelCount == 0) return hipSuccess;
+    uint32_t blocks = (pixelCount + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pt_resolve_kernel, dim3(blocks), dim3(256), 0, stream, accumulation, output, pixelCount);
+    return hipGetLastError();
+}
+
+} // namespace hrt

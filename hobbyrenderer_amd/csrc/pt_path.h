@@ -1,0 +1,311 @@
+// pt_path.h -- the per-path stages of PathTracer_CSMain (/root/reference/src/shaders/PathTracer.hlsl:53-340)
+// as device functions that both the validation megakernel and the wavefront kernels call:
+//   primary_ray        :61-72     TraceRayStandard  RaytracingCommon.hlsli:138-198
+//   shade_surface_a    :92-261    (attributes, transmission branch, emissive, NEE sample generation)
+//   shade_surface_b    :264-313   (Russian roulette, BRDF lobe pick + sample, ray advance)
+//   shadow_query       CommonLighting.hlsli:380-496 (CalculateRTShadow<true>)
+//   miss_sky           :315-328
+// NEE shadow rays draw no random numbers, so a stage may defer them: shade_surface_a hands every
+// light sample to an `emit` callback (direction, distance, unshadowed diffuse/specular radiance).
+#pragma once
+
+#include "pt_device.h"
+
+namespace hrt {
+
+struct PathState {
+    Ray ray;
+    uint32_t rng;
+    f3 throughput, radiance;
+    // dielectric medium the current segment travels in (PathTracer.hlsl:78-81)
+    bool inVolume; float interiorIOR; f3 sigmaA, sigmaS;
+};
+
+// what shade_surface_a needs to keep for shade_surface_b
+struct SurfaceCarry {
+    f3 N, V, worldPos, baseColor, F0; float Fr, roughness, metallic;
+};
+
+HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_t px, uint32_t py)
+{
+    // primary ray, PathTracer.hlsl:61-72; UVToClipXY Common.hlsli:50-53
+    float u = (((float)px + 0.5f) + cb.m_Jitter[0]) * cb.m_View.m_ViewportSizeInv[0];
+    float v = (((float)py + 0.5f) + cb.m_Jitter[1]) * cb.m_View.m_ViewportSizeInv[1];
+    float cx = u * 2.0f + -1.0f, cy = v * -2.0f + 1.0f;
+    const float* M = cb.m_View.m_MatClipToWorldNoOffset;
+    float ex = ((cx * M[0] + cy * M[4]) + 0.9f * M[8]) + 1.0f * M[12];
+    float ey = ((cx * M[1] + cy * M[5]) + 0.9f * M[9]) + 1.0f * M[13];
+    float ez = ((cx * M[2] + cy * M[6]) + 0.9f * M[10]) + 1.0f * M[14];
+    float ew = ((cx * M[3] + cy * M[7]) + 0.9f * M[11]) + 1.0f * M[15];
+    f3 end = mk3(ex / ew, ey / ew, ez / ew);
+    ps.ray.o = mk3(cb.m_CameraPos[0], cb.m_CameraPos[1], cb.m_CameraPos[2]);
+    ps.ray.d = normalize(end - ps.ray.o);
+    ps.ray.tmin = 0.0f; ps.ray.tmax = 1e10f;
+    ps.rng = hrt_rng_seed(px, py, cb.m_AccumulationIndex);        // RNG.hlsli:21-27
+    ps.throughput = mk3(1.0f, 1.0f, 1.0f); ps.radiance = mk3(0.0f, 0.0f, 0.0f);
+    ps.inVolume = false; ps.interiorIOR = 1.0f; ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f);
+}
+
+// TraceRayStandard, RaytracingCommon.hlsli:138-198. Non-opaque candidates are visited front to back:
+// a rejected candidate becomes the exclusive lower bound of the next closest-hit query.
+template <class BVH, class STACK>
+HRT_DEV bool trace_standard(const SceneView& s, const BVH& bvh, const Ray& ray, uint32_t& rng, STACK& stack, Hit& out)
+{
+    HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
+    for (;;) {
+        Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+        if (!h.valid) return false;
+        if (h.opaque) { out = h; return true; }
+        const HrptPerInstanceData& inst = s.instances[h.inst];
+        const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
+        uint32_t alphaMode = mat.m_AlphaMode;
+        bool commit = false;
+        if (alphaMode == HRPT_ALPHA_MODE_MASK || (alphaMode == HRPT_ALPHA_MODE_BLEND && !(mat.m_TransmissionFactor > 0.0f))) {
+            Vtx tv[3]; get_triangle_vertices(s, h.prim, s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[0], tv, false);
+            f2 uv = interpolated_uv(tv, h.u, h.v);
+            float alpha = candidate_alpha(s, mat, uv);
+            if (alphaMode == HRPT_ALPHA_MODE_MASK) commit = alpha >= mat.m_AlphaCutoff;      // AlphaTest :91-110
+            else commit = hrt_rng_next(&rng) < hrt_saturate(alpha);                          // stochastic coverage :181
+        } else if (alphaMode == HRPT_ALPHA_MODE_BLEND) commit = true;                        // transmissive: BSDF decides :181
+        if (commit) { out = h; return true; }
+        lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
+    }
+}
+
+// CalculateRTShadow<true>, CommonLighting.hlsli:380-496.
+template <class BVH, class STACK>
+HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack)
+{
+    const float kShadowBias = 0.01f;
+    Ray ray; ray.o = worldPos; ray.d = L; ray.tmin = kShadowBias; ray.tmax = hrt_max(kShadowBias, maxDist - kShadowBias * 2.0f);
+    // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
+    bool sawNonOpaque;
+    if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque)) return 0.0f;
+    if (!sawNonOpaque) return 1.0f;
+    // Non-opaque candidates, front to back.
+    float transmission = 1.0f; bool inVolume = false; float inVolumeStartT = 0.0f; f3 sigmaT = mk3(0.0f, 0.0f, 0.0f);
+    HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
+    for (;;) {
+        Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+        if (!h.valid) break;
+        const HrptPerInstanceData& inst = s.instances[h.inst];
+        const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
+        uint32_t indexBase = s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[inst.m_LODIndex];   // inst.m_LODIndex, :423
+        Vtx tv[3]; get_triangle_vertices(s, h.prim, indexBase, tv, false);
+        f2 uv = interpolated_uv(tv, h.u, h.v);
+        if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
+            // AlphaTestGrad on single-mip textures == level-0 sample at the interpolated uv (RaytracingCommon.hlsli:112-130,207-240)
+            if (candidate_alpha(s, mat, uv) >= mat.m_AlphaCutoff) return 0.0f;
+        } else if (mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {
+            float alpha = candidate_alpha(s, mat, uv);
+            float opacity = hrt_saturate(alpha * (1.0f - mat.m_TransmissionFactor));
+            transmission *= (1.0f - opacity);
+            if (mat.m_TransmissionFactor > 0.0f && mat.m_IsThinSurface == 0) {
+                float w0 = (1.0f - h.u) - h.v;
+                f3 ln = (tv[0].normal * w0 + tv[1].normal * h.u) + tv[2].normal * h.v;
+                f3 wn = normalize(transform_normal(ln, inst.m_World));
+                bool front = dot(wn, ray.d) < 0.0f;
+                if (front) { inVolume = true; inVolumeStartT = h.t; sigmaT = mk3(mat.m_SigmaA) + mk3(mat.m_SigmaS); }
+                else if (inVolume) {
+                    float seg = hrt_max(0.0f, h.t - inVolumeStartT);
+                    f3 tr = mk3(hrt_exp(-sigmaT.x * seg), hrt_exp(-sigmaT.y * seg), hrt_exp(-sigmaT.z * seg));
+                    transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+                    inVolume = false;
+                }
+            }
+            if (transmission <= 1e-3f) return 0.0f;
+        } else return 0.0f;
+        lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
+    }
+    if (inVolume) {
+        float seg = hrt_max(0.0f, ray.tmax - inVolumeStartT);
+        f3 tr = mk3(hrt_exp(-sigmaT.x * seg), hrt_exp(-sigmaT.y * seg), hrt_exp(-sigmaT.z * seg));
+        transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+    }
+    return hrt_saturate(transmission);
+}
+
+// One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908): early-outs, the jittered sample
+// (2 RNG draws when reached), per-sample byproducts and the unshadowed EvaluateDirectLight terms.
+// Returns false when the light contributes nothing and casts no shadow ray.
+HRT_DEV bool nee_sample(const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunRadiance, f3 sunDirection, float cosSun,
+                        uint32_t& rng, f3& L, float& maxDist, f3& diffuse, f3& specular)
+{
+    f3 radiance;
+    if (l.m_Type == HRPT_LIGHT_DIRECTIONAL) {                                   // :716-745
+        if (dot(in.N, sunDirection) <= 0.0f) return false;
+        radiance = sunRadiance;
+        float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
+        L = sample_cone(sunDirection, cosSun, ux, uy);
+        maxDist = 1e10f;
+    } else if (l.m_Type == HRPT_LIGHT_POINT || l.m_Type == HRPT_LIGHT_SPOT) {   // :752-804, :809-874
+        if (l.m_Intensity <= 0.0f) return false;
+        f3 lp = mk3(l.m_Position);
+        f3 toLight = lp - worldPos;
+        float distSq = dot(toLight, toLight);
+        if (l.m_Range > 0.0f && distSq > l.m_Range * l.m_Range) return false;
+        float dist = hrt_sqrt(distSq);
+        float spotAtt = 1.0f;
+        if (l.m_Type == HRPT_LIGHT_SPOT) {
+            f3 Lc = toLight / dist;
+            if (dot(in.N, Lc) <= 0.0f) return false;
+            f3 lightDir = normalize(mk3(l.m_Direction));
+            float cosTheta = dot(-Lc, lightDir);
+            float cosOuter = hrt_cos(l.m_SpotOuterConeAngle);
+            if (cosTheta < cosOuter) return false;
+            float cosInner = hrt_cos(l.m_SpotInnerConeAngle);
+            spotAtt = hrt_saturate((cosTheta - cosOuter) / (cosInner - cosOuter));
+        }
+        float att = distance_attenuation(l, distSq, dist);
+        f3 col = mk3(l.m_Color);
+        radiance = (l.m_Type == HRPT_LIGHT_SPOT) ? ((col * l.m_Intensity) * spotAtt) * att : (col * l.m_Intensity) * att;
+        float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
+        float cosT = 1.0f - 2.0f * ux;
+        float sinT = hrt_sqrt(hrt_max(0.0f, 1.0f - cosT * cosT));
+        float phi = 2.0f * HRT_PI * uy;
+        float sp, cp; hrt_sincos(phi, &sp, &cp);
+        f3 sphereDir = mk3(sinT * cp, cosT, sinT * sp);
+        f3 samplePos = lp + sphereDir * l.m_Radius;
+        f3 toSample = samplePos - worldPos;
+        float sampleDist = length(toSample);
+        L = toSample / sampleDist;
+        maxDist = sampleDist;
+    } else return false;
+    if (dot(in.N, L) <= 0.0f) return false;
+    in.L = L;
+    prepare_byproducts(in);
+    evaluate_direct_unshadowed(in, radiance, diffuse, specular);
+    return true;
+}
+
+enum SurfaceOutcome { SURFACE_TRANSMITTED = 0, SURFACE_SCATTER = 1 };
+
+// PathTracer.hlsl:92-261 up to the light loop. EMIT(lightOrdinal, worldPos, L, maxDist, diffuse, specular) receives
+// each light sample; the caller owes  radiance += neeThroughput * (sum(diffuse_i*shadow_i) + (bounce==0 ? sum(specular_i*shadow_i) : 0)).
+template <class EMIT>
+HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, const Hit& hit,
+                                       SurfaceCarry& carry, EMIT&& emit)
+{
+    const HrptPerInstanceData& inst = s.instances[hit.inst];
+    const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
+    uint32_t indexBase = s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[0];      // LOD 0, :103
+    uint32_t texFlags = mat.m_TextureFlags;
+
+    if (ps.inVolume) {                                                            // Beer-Lambert :97-100
+        f3 tr = mk3(hrt_exp(-(ps.sigmaA.x + ps.sigmaS.x) * hit.t), hrt_exp(-(ps.sigmaA.y + ps.sigmaS.y) * hit.t),
+                    hrt_exp(-(ps.sigmaA.z + ps.sigmaS.z) * hit.t));
+        ps.throughput = ps.throughput * tr;
+    }
+    SurfaceAttr attr = full_hit_attributes(s, hit, ps.ray, inst, indexBase, (texFlags & HRPT_TEXFLAG_NORMAL) != 0);
+    Pbr pbr = pbr_attributes(s, attr, mat);
+
+    f3 p_atmo = atm::atmosphere_pos(attr.worldPos);
+    f3 Ng = normalize(attr.worldNormal);
+    f3 N = pbr.normal;
+    f3 V = -ps.ray.d;
+    bool isFrontFace = dot(Ng, ps.ray.d) < 0.0f;
+    if (dot(N, V) < 0.0f) N = -N;
+
+    f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+    float sunIntensity = s.lights[0].m_Intensity;                                 // g_Lights[0] :137 (reference quirk kept)
+
+    Lighting in;
+    in.N = N; in.V = V; in.L = mk3(0.0f, 0.0f, 0.0f); in.baseColor = pbr.baseColor;
+    in.roughness = pbr.roughness; in.metallic = pbr.metallic; in.ior = mat.m_IOR;
+    f3 sunRadiance = atm::sun_radiance(s, p_atmo, sunDir, sunIntensity);
+    prepare_byproducts(in);                                                       // :142 (L = 0 => H = V)
+
+    if (mat.m_TransmissionFactor > 0.0f || mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {    // :149-255
+        float effectiveAlpha = (mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) ? pbr.alpha : 1.0f;
+        float transmissionFactor = hrt_max(mat.m_TransmissionFactor, 1.0f - effectiveAlpha);
+        float materialIOR = hrt_max(mat.m_IOR, 1.0001f);
+        float outsideIOR = ps.inVolume ? ps.interiorIOR : 1.0f;
+        float etaSurface = isFrontFace ? (outsideIOR / materialIOR) : (materialIOR / outsideIOR);
+        float etaFresnel = etaSurface;
+        float etaRefract = (mat.m_IsThinSurface != 0) ? 1.0f : etaFresnel;
+        float cosT_geo;
+        float F = fresnel_dielectric(etaFresnel, hrt_max(dot(N, V), 0.0f), cosT_geo);
+        float probT = hrt_saturate((1.0f - F) * transmissionFactor);
+        if (hrt_rng_next(&ps.rng) < probT) {
+            f3 refractedDir, bsdfWeight;
+            if (pbr.roughness <= 0.08f) {
+                refractedDir = refract(ps.ray.d, N, etaRefract);
+                if (dot(refractedDir, refractedDir) < 1e-8f) refractedDir = reflect(ps.ray.d, N);
+                bsdfWeight = pbr.baseColor;
+            } else {
+                float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
+                f3 H = sample_ggx_vndf(ux, uy, N, V, pbr.roughness);
+                float VdotH = hrt_saturate(dot(V, H));
+                float cosT_mf; float F_mf = fresnel_dielectric(etaFresnel, VdotH, cosT_mf);
+                float cosT_dir; fresnel_dielectric(etaRefract, VdotH, cosT_dir);
+                refractedDir = H * (etaRefract * VdotH - cosT_dir) - V * etaRefract;
+                if (dot(refractedDir, refractedDir) < 1e-8f) refractedDir = reflect(ps.ray.d, H);
+                refractedDir = normalize(refractedDir);
+                float alpha = pbr.roughness * pbr.roughness, alpha2 = alpha * alpha;
+                float NdotL_t = hrt_abs(dot(N, refractedDir));
+                float G1_t = (NdotL_t > 1e-5f) ? 2.0f * NdotL_t / (NdotL_t + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL_t * NdotL_t)) : 0.0f;
+                bsdfWeight = ((pbr.baseColor * (1.0f - F_mf)) * G1_t) * NdotL_t;
+            }
+            ps.throughput = ps.throughput * bsdfWeight;
+            if (mat.m_IsThinSurface == 0) {
+                if (isFrontFace) { ps.inVolume = true; ps.interiorIOR = materialIOR; ps.sigmaA = mk3(mat.m_SigmaA); ps.sigmaS = mk3(mat.m_SigmaS); }
+                else { ps.inVolume = false; ps.interiorIOR = 1.0f; ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); }
+            }
+            ps.ray.o = attr.worldPos - N * 0.001f;
+            ps.ray.d = normalize(refractedDir);
+            ps.ray.tmin = 1e-4f; ps.ray.tmax = 1e10f;
+            return SURFACE_TRANSMITTED;
+        }
+    }
+
+    ps.radiance = ps.radiance + ps.throughput * pbr.emissive;                     // :258
+
+    for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
+        HrptGPULight l;
+        if (i < s.lightCount) l = s.lights[i]; else { l = HrptGPULight(); l.m_Type = 0; }   // OOB structured read = zeros
+        f3 L, dif, spec; float maxDist;
+        if (nee_sample(l, in, attr.worldPos, sunRadiance, sunDir, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
+            emit(i, attr.worldPos, L, maxDist, dif, spec);
+    }
+    carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;
+    carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic;
+    return SURFACE_SCATTER;
+}
+
+// PathTracer.hlsl:264-313. Returns false when the path ends.
+HRT_DEV bool shade_surface_b(PathState& ps, const SurfaceCarry& c, int bounce)
+{
+    if (bounce >= 2) {                                                            // Russian roulette :264-270
+        float continuePr = hrt_saturate(maxcomp(ps.throughput));
+        if (hrt_rng_next(&ps.rng) > continuePr) return false;
+        ps.throughput = ps.throughput / continuePr;
+    }
+    float specProb = hrt_clamp(lerp(c.Fr * 0.5f + 0.5f * c.metallic, 1.0f, c.metallic), 0.1f, 0.9f);   // :275
+    f3 newDir, brdfWeight;
+    if (hrt_rng_next(&ps.rng) < specProb) {
+        float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
+        f3 H = sample_ggx_vndf(ux, uy, c.N, c.V, c.roughness);
+        newDir = reflect(-c.V, H);
+        if (dot(c.N, newDir) <= 0.0f) return false;
+        brdfWeight = eval_ggx_vndf_weight(c.F0, c.N, c.V, newDir, H, c.roughness) / specProb;
+    } else {
+        float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
+        newDir = sample_hemisphere_cosine(ux, uy, c.N);
+        if (dot(c.N, newDir) <= 0.0f) return false;
+        brdfWeight = (c.baseColor * (1.0f - c.metallic)) / (1.0f - specProb);
+    }
+    ps.throughput = ps.throughput * brdfWeight;
+    if (maxcomp(ps.throughput) < 0.01f) return false;                             // :306
+    ps.ray.o = c.worldPos; ps.ray.d = newDir; ps.ray.tmin = 1e-4f; ps.ray.tmax = 1e10f;   // :310-313
+    return true;
+}
+
+// PathTracer.hlsl:315-328
+HRT_DEV void miss_sky(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, int bounce)
+{
+    f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+    f3 sky = atm::sky_radiance(s, ps.ray.o, ps.ray.d, sunDir, s.lights[0].m_Intensity, bounce == 0);
+    ps.radiance = ps.radiance + ps.throughput * sky;
+}
+
+} // namespace hrt

@@ -1,0 +1,139 @@
+"""ctypes binding of libhobbyrt_pt.so (include/hobbyrt_pt.h). There is no fallback: if the in-tree HIP
+library is missing this module raises at import, and if no GPU is present hrpt_create fails."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import structs as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhobbyrt_pt.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C hobbyrenderer_amd/csrc` (or __graft_entry__.build()). "
+        "The HIP library is the only backend of this package.")
+
+lib = C.CDLL(LIB_PATH)
+
+EXPORTS = [
+    "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
+    "hrpt_synchronize", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_halton",
+    "hrpt_precompute_atmosphere",
+]
+
+lib.hrpt_create.argtypes = [C.POINTER(S.DeviceDesc), C.POINTER(C.c_void_p)]
+lib.hrpt_destroy.argtypes = [C.c_void_p]
+lib.hrpt_destroy.restype = None
+lib.hrpt_last_error.argtypes = [C.c_void_p]
+lib.hrpt_last_error.restype = C.c_char_p
+lib.hrpt_upload_scene.argtypes = [C.c_void_p, C.POINTER(S.SceneDesc)]
+lib.hrpt_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+lib.hrpt_render.argtypes = [C.c_void_p, C.c_void_p]
+lib.hrpt_synchronize.argtypes = [C.c_void_p]
+lib.hrpt_get_device_images.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+lib.hrpt_read_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.hrpt_read_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.hrpt_write_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.hrpt_resolve_output.argtypes = [C.c_void_p]
+lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
+lib.hrpt_reset_stats.argtypes = [C.c_void_p]
+lib.hrpt_halton.argtypes = [C.c_uint32, C.c_uint32]
+lib.hrpt_halton.restype = C.c_float
+lib.hrpt_precompute_atmosphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+
+
+class HrptError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"hrpt error {code}: {message}")
+        self.code = code
+
+
+def precompute_atmosphere(nthreads=0):
+    """Stand-ins for bin/bruneton/*.dat (src/CommonResources.cpp:519-569): float32 RGBA tables."""
+    t = np.zeros(S.LUT_TRANSMITTANCE_SHAPE, np.float32)
+    s = np.zeros(S.LUT_SCATTERING_SHAPE, np.float32)
+    i = np.zeros(S.LUT_IRRADIANCE_SHAPE, np.float32)
+    rc = lib.hrpt_precompute_atmosphere(t.ctypes.data, s.ctypes.data, i.ctypes.data, nthreads)
+    if rc != 0:
+        raise HrptError(rc, "hrpt_precompute_atmosphere")
+    return t, s, i
+
+
+class PathTracerContext:
+    """One context = one GPU = one stream (include/hobbyrt_pt.h)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        desc = S.DeviceDesc(device, 1)
+        rc = lib.hrpt_create(C.byref(desc), C.byref(self._h))
+        if rc != 0:
+            raise HrptError(rc, lib.hrpt_last_error(None).decode())
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HrptError(rc, lib.hrpt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib.hrpt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, scene):
+        d, keep = scene.desc()
+        self._check(lib.hrpt_upload_scene(self._h, C.byref(d)))
+        del keep
+
+    def resize(self, width, height):
+        self._check(lib.hrpt_resize(self._h, width, height))
+        self.width, self.height = width, height
+
+    def render(self, constants, accum_count=1, tile=(0, 0, 0, 0), flags=S.FRAME_DEFAULT):
+        p = np.zeros((), S.FrameParams)
+        p["constants"] = constants
+        p["accumCount"] = accum_count
+        p["tileX0"], p["tileY0"], p["tileX1"], p["tileY1"] = tile
+        p["flags"] = flags
+        self._check(lib.hrpt_render(self._h, p.ctypes.data))
+
+    def synchronize(self):
+        self._check(lib.hrpt_synchronize(self._h))
+
+    def device_images(self):
+        a, o = C.c_void_p(), C.c_void_p()
+        self._check(lib.hrpt_get_device_images(self._h, C.byref(a), C.byref(o)))
+        return a.value, o.value
+
+    def read_accumulation(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib.hrpt_read_accumulation(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_output(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib.hrpt_read_output(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def write_accumulation(self, img):
+        img = np.ascontiguousarray(img, np.float32)
+        self._check(lib.hrpt_write_accumulation(self._h, img.ctypes.data, img.nbytes))
+
+    def resolve_output(self):
+        self._check(lib.hrpt_resolve_output(self._h))
+
+    def stats(self):
+        st = S.Stats()
+        self._check(lib.hrpt_get_stats(self._h, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        self._check(lib.hrpt_reset_stats(self._h))

@@ -1,0 +1,295 @@
+/*
+ * hobbyrt_pt.h -- C ABI of libhobbyrt_pt.so, the MI355X (gfx950) drop-in for the
+ * reference path-tracer pass of lawfuyang/HobbyRenderer.
+ *
+ * What it replaces (reference file:line, all under /root/reference):
+ *   - the GPU work of PathTracerRenderer::Render, src/PathTracerRenderer.cpp:31-106:
+ *     writeBuffer(PathTracerCB) + PathTracerInputs binding + dispatch of
+ *     PathTracer_CSMain (src/shaders/PathTracer.hlsl:53-340);
+ *   - the acceleration structures of Scene::BuildAccelerationStructures,
+ *     src/Scene.cpp:67-214 (driver BLAS/TLAS -> library-owned BVH);
+ *   - the scene buffer uploads of SceneLoader::CreateAndUploadGpuBuffers /
+ *     CreateAndUploadLightBuffer, src/SceneLoader.cpp:2319-2493;
+ *   - the Bruneton LUT upload of CommonResources, src/CommonResources.cpp:519-569.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no exceptions, no torch types.
+ * Every call returns HRPT_OK (0) or a negative HrptStatus; the message of the last
+ * failure on a context is available from hrpt_last_error(). The reference has no
+ * return codes (SDL_assert + log, src/pch.h:77); a reference-side caller asserts on
+ * != HRPT_OK. One context = one GPU = one HIP stream; calls on one context must be
+ * serialised by the caller, different contexts may be driven from different threads
+ * (mirrors: Render runs on a TaskScheduler worker with its own command list,
+ * src/RenderGraph.cpp:329-349).
+ *
+ * All struct layouts are the structured-buffer / cbuffer layouts of the reference
+ * shaders (the .sr files under src/shaders); sizes are checked with static asserts below.
+ */
+#ifndef HOBBYRT_PT_H
+#define HOBBYRT_PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRPT_ABI_VERSION 1
+
+typedef enum HrptStatus {
+    HRPT_OK = 0,
+    HRPT_ERR_INVALID_ARGUMENT = -1,   /* null pointer, bad size, index out of range in scene data */
+    HRPT_ERR_NO_DEVICE = -2,          /* no HIP device / device ordinal out of range */
+    HRPT_ERR_HIP = -3,                /* a HIP runtime call failed; see hrpt_last_error */
+    HRPT_ERR_NO_SCENE = -4,           /* render before upload_scene */
+    HRPT_ERR_OUT_OF_MEMORY = -5,
+    HRPT_ERR_UNSUPPORTED = -6
+} HrptStatus;
+
+/* ---- GPU struct layouts (src/shaders/Mesh.sr, Instance.sr, GPULight.sr, Common.sr, PathTracer.sr) ---- */
+
+typedef struct HrptVertexQuantized {       /* Mesh.sr:9-15, 24 B */
+    float    m_Pos[3];
+    uint32_t m_Normal;                     /* 10:10:10 snorm+511, bit 30 = tangent sign (1 => -1) */
+    uint32_t m_Uv;                         /* 2 x fp16 */
+    uint32_t m_Tangent;                    /* 8:8 octahedral +127 */
+} HrptVertexQuantized;
+
+typedef struct HrptMeshData {              /* Mesh.sr:17-25, 164 B */
+    uint32_t m_LODCount;
+    uint32_t m_IndexOffsets[8];
+    uint32_t m_IndexCounts[8];
+    uint32_t m_MeshletOffsets[8];
+    uint32_t m_MeshletCounts[8];
+    float    m_LODErrors[8];
+} HrptMeshData;
+
+typedef struct HrptPerInstanceData {       /* Instance.sr:49-65, 160 B */
+    float    m_World[16];                  /* row-major, row-vector convention: p_world = p * M, translation in row 3 */
+    float    m_PrevWorld[16];
+    uint32_t m_MaterialIndex;
+    uint32_t m_MeshDataIndex;
+    float    m_Radius;
+    uint32_t m_LODIndex;
+    float    m_Center[3];
+    uint32_t m_FirstGeometryInstanceIndex;
+} HrptPerInstanceData;
+
+typedef struct HrptMaterialConstants {     /* Instance.sr:2-46, 180 B */
+    float    m_BaseColor[4];
+    float    m_EmissiveFactor[4];
+    float    m_RoughnessMetallic[2];
+    uint32_t m_TextureFlags;
+    uint32_t m_AlbedoTextureIndex;
+    uint32_t m_NormalTextureIndex;
+    uint32_t m_RoughnessMetallicTextureIndex;
+    uint32_t m_EmissiveTextureIndex;
+    uint32_t m_AlbedoSamplerIndex;
+    uint32_t m_NormalSamplerIndex;
+    uint32_t m_RoughnessSamplerIndex;
+    uint32_t m_EmissiveSamplerIndex;
+    uint32_t m_AlbedoMinMipIndex;
+    uint32_t m_NormalMinMipIndex;
+    uint32_t m_RoughnessMinMipIndex;
+    uint32_t m_EmissiveMinMipIndex;
+    uint32_t m_AlbedoFeedbackIndex;
+    uint32_t m_NormalFeedbackIndex;
+    uint32_t m_RoughnessFeedbackIndex;
+    uint32_t m_EmissiveFeedbackIndex;
+    uint32_t m_MinMipDimsX;
+    uint32_t m_MinMipDimsY;
+    uint32_t m_AlphaMode;
+    float    m_AlphaCutoff;
+    float    m_IOR;
+    float    m_TransmissionFactor;
+    float    m_ThicknessFactor;
+    float    m_AttenuationDistance;
+    float    m_AttenuationColor[3];
+    float    m_SigmaA[3];
+    uint32_t m_IsThinSurface;
+    float    m_SigmaS[3];
+} HrptMaterialConstants;
+
+typedef struct HrptGPULight {              /* GPULight.sr:1-13, 64 B */
+    float    m_Position[3];
+    float    m_Intensity;
+    float    m_Direction[3];
+    uint32_t m_Type;                       /* 0 directional, 1 point, 2 spot */
+    float    m_Color[3];
+    float    m_Range;
+    float    m_SpotInnerConeAngle;
+    float    m_SpotOuterConeAngle;
+    float    m_Radius;
+    float    m_CosSunAngularRadius;
+} HrptGPULight;
+
+typedef struct HrptPlanarViewConstants {   /* Common.sr:17-43, 704 B */
+    float m_MatWorldToView[16];
+    float m_MatViewToClip[16];
+    float m_MatWorldToClip[16];
+    float m_MatClipToView[16];
+    float m_MatViewToWorld[16];
+    float m_MatClipToWorld[16];
+    float m_MatViewToClipNoOffset[16];
+    float m_MatWorldToClipNoOffset[16];
+    float m_MatClipToViewNoOffset[16];
+    float m_MatClipToWorldNoOffset[16];
+    float m_ViewportOrigin[2];
+    float m_ViewportSize[2];
+    float m_ViewportSizeInv[2];
+    float m_PixelOffset[2];
+    float m_ClipToWindowScale[2];
+    float m_ClipToWindowBias[2];
+    float m_CameraDirectionOrPosition[4];
+} HrptPlanarViewConstants;
+
+/* cbuffer PathTracerConstants, PathTracer.sr:6-17, 768 B (offsets follow HLSL cbuffer
+ * packing; the generated srrhi header is not in the reference tree). */
+typedef struct HrptPathTracerConstants {
+    HrptPlanarViewConstants m_View;        /* @0   */
+    float    m_CameraPos[4];               /* @704 */
+    uint32_t m_LightCount;                 /* @720 */
+    uint32_t m_AccumulationIndex;          /* @724 */
+    uint32_t m_FrameIndex;                 /* @728 (written, never read by the shader) */
+    uint32_t m_MaxBounces;                 /* @732 */
+    float    m_Jitter[2];                  /* @736 */
+    float    m_Pad0[2];                    /* @744 (float3 may not straddle a 16-byte row) */
+    float    m_SunDirection[3];            /* @752 */
+    float    m_CosSunAngularRadius;        /* @764 */
+} HrptPathTracerConstants;
+
+/* CommonConsts (Common.sr:47-140) used on this path */
+enum {
+    HRPT_TEXFLAG_ALBEDO = 1, HRPT_TEXFLAG_NORMAL = 2, HRPT_TEXFLAG_ROUGHNESS_METALLIC = 4, HRPT_TEXFLAG_EMISSIVE = 8,
+    HRPT_ALPHA_MODE_OPAQUE = 0, HRPT_ALPHA_MODE_MASK = 1, HRPT_ALPHA_MODE_BLEND = 2,
+    HRPT_TRANSMITTANCE_TEXTURE_WIDTH = 256, HRPT_TRANSMITTANCE_TEXTURE_HEIGHT = 64,
+    HRPT_SCATTERING_TEXTURE_WIDTH = 256, HRPT_SCATTERING_TEXTURE_HEIGHT = 128, HRPT_SCATTERING_TEXTURE_DEPTH = 32,
+    HRPT_IRRADIANCE_TEXTURE_WIDTH = 64, HRPT_IRRADIANCE_TEXTURE_HEIGHT = 16,
+    HRPT_LIGHT_DIRECTIONAL = 0, HRPT_LIGHT_POINT = 1, HRPT_LIGHT_SPOT = 2
+};
+
+/* A bindless 2D texture as the stb path of the reference produces it: RGBA8_UNORM,
+ * one mip, no sRGB decode (src/TextureLoader.cpp:249-250). */
+typedef struct HrptTextureDesc {
+    const uint8_t* rgba8;                  /* width*height*4 bytes, row-major, may be NULL for an unused slot */
+    uint32_t width, height;
+} HrptTextureDesc;
+
+/* Everything the reference binds to PathTracerInputs (PathTracer.sr:19-32) plus the
+ * global bindless tables it reads (src/Renderer.cpp:1834-1841). Host pointers; the
+ * library copies during hrpt_upload_scene and the caller keeps ownership. */
+typedef struct HrptSceneDesc {
+    const HrptVertexQuantized*   vertices;   uint32_t vertexCount;     /* Scene::m_VertexBufferQuantized */
+    const uint32_t*              indices;    uint32_t indexCount;      /* Scene::m_IndexBuffer (global vertex indices) */
+    const HrptMeshData*          meshData;   uint32_t meshDataCount;   /* Scene::m_MeshData */
+    const HrptPerInstanceData*   instances;  uint32_t instanceCount;   /* Scene::m_InstanceData; index == TLAS instanceID */
+    const HrptMaterialConstants* materials;  uint32_t materialCount;   /* MaterialConstantsFromMaterial output */
+    const HrptGPULight*          lights;     uint32_t lightCount;      /* CreateAndUploadLightBuffer order */
+    /* bindless Texture2D table, index = MaterialConstants::m_*TextureIndex. Slots 0..10 are the
+     * reference's default textures (Common.sr:103-113); entries with rgba8 == NULL are unbound. */
+    const HrptTextureDesc*       textures;   uint32_t textureCount;
+    /* Bruneton LUTs in the file format of bin/bruneton/{transmittance,scattering,irradiance}.dat: raw float32 RGBA. The library
+     * converts to RGBA16F like CommonResources.cpp:550-558. irradiance may be NULL (not read on this path). */
+    const float* brunetonTransmittance;    /* 256*64*4 floats */
+    const float* brunetonScattering;       /* 256*128*32*4 floats */
+    const float* brunetonIrradiance;       /* 64*16*4 floats or NULL */
+} HrptSceneDesc;
+
+typedef struct HrptDeviceDesc {
+    int32_t  deviceOrdinal;                /* HIP device index */
+    uint32_t abiVersion;                   /* HRPT_ABI_VERSION */
+} HrptDeviceDesc;
+
+/* One dispatch of the reference == one accumulation index. `accumCount` > 1 renders
+ * indices first..first+accumCount-1 in one call (the "spp" of BASELINE.json); the
+ * per-index jitter / accumulation-index fields of `constants` are then recomputed
+ * by the library exactly as PathTracerRenderer::Render does (:62,:65). */
+typedef struct HrptFrameParams {
+    HrptPathTracerConstants constants;     /* as filled by PathTracerRenderer::Render :58-75 for the FIRST index */
+    uint32_t accumCount;                   /* >= 1 */
+    /* pixel rectangle [x0,x1) x [y0,y1) rendered by this context (image-tile sharding); 0,0,0,0 = full viewport */
+    uint32_t tileX0, tileY0, tileX1, tileY1;
+    uint32_t flags;                        /* HRPT_FRAME_* */
+} HrptFrameParams;
+
+enum {
+    HRPT_FRAME_DEFAULT = 0,
+    HRPT_FRAME_MEGAKERNEL = 1,             /* one-thread-per-pixel restatement kernel (validation path) */
+    HRPT_FRAME_WAVEFRONT = 2               /* persistent wavefront pipeline (default when available) */
+};
+
+typedef struct HrptStats {
+    uint64_t closestRays;                  /* TraceRayStandard queries launched */
+    uint64_t shadowRays;                   /* CalculateRTShadow queries launched */
+    uint64_t paths;                        /* pixel-paths started */
+    float    lastRenderMs;                 /* device time of the last hrpt_render (HIP events on the context stream) */
+    float    traceKernelMs;                /* summed device time of the dominant (trace) kernel in the last render */
+    uint32_t traceKernelLaunches;
+    uint32_t bvhNodeCount;
+    uint32_t bvhTriangleCount;
+    uint32_t pad;
+} HrptStats;
+
+typedef struct HrptContext HrptContext;
+
+int  hrpt_create(const HrptDeviceDesc* desc, HrptContext** out);
+void hrpt_destroy(HrptContext* ctx);
+const char* hrpt_last_error(const HrptContext* ctx);      /* ctx may be NULL: last creation error */
+
+/* Replaces scene buffer upload + BLAS/TLAS build. Validates every index in the scene data. */
+int  hrpt_upload_scene(HrptContext* ctx, const HrptSceneDesc* scene);
+
+/* (Re)allocates the RGBA32F Accumulation (u1) and Output (u0) images, PathTracerRenderer::Setup :14-29. */
+int  hrpt_resize(HrptContext* ctx, uint32_t width, uint32_t height);
+
+/* The dispatch. Asynchronous on the context stream. */
+int  hrpt_render(HrptContext* ctx, const HrptFrameParams* params);
+int  hrpt_synchronize(HrptContext* ctx);
+
+/* Device pointers of the two images (width*height float4, row-major) for zero-copy consumers
+ * (the HDR post chain, RCCL all-gather). */
+int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output);
+/* Host read-back (synchronises). bytes must be width*height*16. */
+int  hrpt_read_accumulation(HrptContext* ctx, float* rgba, size_t bytes);
+int  hrpt_read_output(HrptContext* ctx, float* rgba, size_t bytes);
+/* Host write of the accumulation image (resume a progressive render). */
+int  hrpt_write_accumulation(HrptContext* ctx, const float* rgba, size_t bytes);
+/* Output = accum.rgb / accum.a for every pixel (PathTracer.hlsl:339), e.g. after an all-gather of accumulation tiles. */
+int  hrpt_resolve_output(HrptContext* ctx);
+
+int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray counters are cumulative */
+int  hrpt_reset_stats(HrptContext* ctx);
+
+/* Host-side helpers of PathTracerRenderer::Render, exported so that callers in other languages
+ * produce the same constants: Halton (src/Utilities.cpp:67-79) and the CB fill (:58-75). */
+float hrpt_halton(uint32_t index, uint32_t base);
+
+/* Host-side producer of stand-ins for bin/bruneton/{transmittance,scattering,irradiance}.dat, which the
+ * reference loads (src/CommonResources.cpp:519-569) but does not ship: raw float32 RGBA tables of
+ * 256*64, 256*128*32 and 64*16 texels from the constants of src/shaders/Atmosphere.hlsli:41-75
+ * (transmittance + single scattering; irradiance is zero-filled and may be NULL). No GPU needed. */
+int  hrpt_precompute_atmosphere(float* transmittance, float* scattering, float* irradiance, int nthreads);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#if defined(__cplusplus)
+static_assert(sizeof(HrptVertexQuantized) == 24, "VertexQuantized");
+static_assert(sizeof(HrptMeshData) == 164, "MeshData");
+static_assert(sizeof(HrptPerInstanceData) == 160, "PerInstanceData");
+static_assert(sizeof(HrptMaterialConstants) == 180, "MaterialConstants");
+static_assert(sizeof(HrptGPULight) == 64, "GPULight");
+static_assert(sizeof(HrptPlanarViewConstants) == 704, "PlanarViewConstants");
+static_assert(sizeof(HrptPathTracerConstants) == 768, "PathTracerConstants");
+#else
+_Static_assert(sizeof(HrptVertexQuantized) == 24, "VertexQuantized");
+_Static_assert(sizeof(HrptMeshData) == 164, "MeshData");
+_Static_assert(sizeof(HrptPerInstanceData) == 160, "PerInstanceData");
+_Static_assert(sizeof(HrptMaterialConstants) == 180, "MaterialConstants");
+_Static_assert(sizeof(HrptGPULight) == 64, "GPULight");
+_Static_assert(sizeof(HrptPlanarViewConstants) == 704, "PlanarViewConstants");
+_Static_assert(sizeof(HrptPathTracerConstants) == 768, "PathTracerConstants");
+#endif
+
+#endif /* HOBBYRT_PT_H */
