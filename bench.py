@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: Mrays/s at 1920x1080, 8 spp, 4 bounces (config 2: Cornell-box-class
+procedural scene) on N MI355X of one node.
+
+A "step" is one full render of that frame through the C ABI (hrpt_render with accumCount = spp) with the
+Scene, BVH and LUTs already resident in HBM. N > 1: one process per GPU (torch.distributed over RCCL), the
+image is sharded by row bands (pixels are independent: RNG.hlsli:21-27), scene replicated, one all-gather of
+the RGBA32F accumulation bands per step, then the resolve (Output = accum.rgb / accum.a). Total work is fixed
+as N grows ("strong" scaling); value is the whole-job aggregate.
+
+Rays = closest-hit queries + shadow queries actually launched (device counters; identical to the oracle's).
+roofline: algorithmic bytes per ray from SURVEY.md 8(d) -- B_closest = 768 + 32 n + 48 t, B_shadow = 36 + 32 n
++ 48 t, + 48 B per pixel per spp -- with n (AABB tests) and t (triangle tests) counted by the CPU oracle on a
+bounded sample of the same workload, divided by the dominant kernel's device time (HIP events recorded by the
+library on its own stream). cpu_baseline: the oracle (a port; the reference has no CPU path) timed on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+class _DevMem:
+    """Exposes a library-owned device buffer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--mode", choices=["default", "megakernel", "wavefront"], default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from hobbyrenderer_amd import native, scenes, structs as S
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
+    luts = native.precompute_atmosphere()
+    sc, view, pos, _ = scenes.config_cornell(luts, W, H)
+    ctx = native.PathTracerContext(local_rank)
+    ctx.upload_scene(sc)
+    ctx.resize(W, H)
+    cb = scenes.fill_constants(view, pos, sc, 0, bounces)
+    flags = {"default": S.FRAME_DEFAULT, "megakernel": S.FRAME_MEGAKERNEL, "wavefront": S.FRAME_WAVEFRONT}[args.mode]
+
+    # row-band sharding; bands are contiguous in the row-major accumulation image
+    if H % world != 0:
+        raise SystemExit(f"height {H} must be divisible by the number of GPUs {world} (equal contiguous all-gather shards)")
+    rows = H // world
+    y0, y1 = rank * rows, (rank + 1) * rows
+    tile = (0, y0, W, y1) if world > 1 else (0, 0, 0, 0)
+    accum_ptr, _ = ctx.device_images()
+    full = torch.as_tensor(_DevMem(accum_ptr, (H, W, 4)), device=dev) if world > 1 else None
+
+    def step():
+        ctx.render(cb, accum_count=spp, tile=tile, flags=flags)
+        if world > 1:
+            ctx.synchronize()                                   # library stream -> host; RCCL runs on torch's stream
+            band = full[y0:y1].clone()                          # 33.18 MB / N per rank
+            dist.all_gather_into_tensor(full, band)             # the single collective of the path
+            torch.cuda.synchronize(dev)
+            ctx.resolve_output()                                # Output = accum.rgb / accum.a on every rank
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ctx.reset_stats()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+
+    tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st.closestRays + st.shadowRays), float(st.closestRays), float(st.shadowRays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(tm.item())
+    total_rays, closest_total, shadow_total = (float(x) for x in rays.tolist())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays / elapsed / 1e6
+        result = {
+            "metric": "Mrays/s at 1920x1080, 8 spp, 4 bounces; 1/2/4/8 GPU scaling",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 2: Cornell-box-class procedural scene (38 triangles, 9 instances, closed room, emissive quad + "
+                                   f"default sun), {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
+                       "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" if world > 1 else ""),
+                       "mode": args.mode, "rays_per_step": total_rays / args.steps,
+                       "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
+        }
+        # ---- cpu_baseline + n/t counters: oracle on a bounded sample (N=1 only; other N reuse the constants below)
+        n_c = t_c = n_s = t_s = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.binding import Oracle, OrStats
+            o = Oracle(sc)
+            ost = OrStats()
+            cores = os.cpu_count() or 1
+            sample_spp = 1
+            t1 = time.perf_counter()
+            o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), W, H, sample_spp, nthreads=cores, stats=ost)
+            cpu_s = time.perf_counter() - t1
+            o.close()
+            d = ost.as_dict()
+            n_c, t_c = d["closestNodes"] / max(1, d["closestRays"]), d["closestTris"] / max(1, d["closestRays"])
+            n_s, t_s = d["shadowNodes"] / max(1, d["shadowRays"]), d["shadowTris"] / max(1, d["shadowRays"])
+            result["cpu_baseline"] = {
+                "value": (d["closestRays"] + d["shadowRays"]) / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"oracle (CPU restatement of the reference shader; the reference has no CPU path), same scene, {W}x{H}, "
+                          f"accumulation index 0 only ({sample_spp} of {spp} spp), {bounces} bounces, {cores} pthreads, {cpu_s:.2f} s"}
+        if n_c is None:
+            # constants measured by the oracle on config 2 (Measurement); used when the oracle leg is skipped
+            n_c, t_c, n_s, t_s = 16.14, 2.60, 17.37, 2.71
+        b_closest = 768.0 + 32.0 * n_c + 48.0 * t_c
+        b_shadow = 36.0 + 32.0 * n_s + 48.0 * t_s
+        r0_closest, r0_shadow = float(st.closestRays) / args.steps, float(st.shadowRays) / args.steps   # rank 0, per step
+        px0 = (y1 - y0) * W if world > 1 else W * H
+        step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
+        if st.traceKernelLaunches > 0:
+            # wavefront: the dominant kernel is the persistent closest-hit trace kernel (one launch per bounce)
+            launches = st.traceKernelLaunches
+            per_launch_bytes = r0_closest * (32.0 + 20.0 + 32.0 * n_c + 48.0 * t_c) / launches   # ray record + hit record + traversal
+            avg_ms = st.traceKernelMs / launches
+            kernel = "pt_wf_extend"
+        else:
+            # megakernel: one launch per accumulation index does the whole dispatch
+            launches = spp
+            per_launch_bytes = step_bytes / spp
+            avg_ms = st.lastRenderMs / spp
+            kernel = "pt_megakernel"
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": None, "kernel": kernel, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                              "algorithmic_bytes_per_launch": per_launch_bytes,
+                              "bytes_per_closest_ray": b_closest, "bytes_per_shadow_ray": b_shadow,
+                              "whole_step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                              "n_closest": n_c, "t_closest": t_c, "n_shadow": n_s, "t_shadow": t_s}
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,12 +180,34 @@ static int32_t build_node(OrContext* c, float* cent, uint32_t first, uint32_t co
     }
     n->left = n->right = -1; n->first = first; n->count = count;
     if (count <= 2) return id;
-    int axis = 0; float ext = cmx[0] - cmn[0];
-    if (cmx[1] - cmn[1] > ext) { axis = 1; ext = cmx[1] - cmn[1]; }
-    if (cmx[2] - cmn[2] > ext) { axis = 2; ext = cmx[2] - cmn[2]; }
-    g_axis = axis; g_cent = cent;
+    /* full-sweep SAH over the three axes (oracle-owned builder; quality matters only for the n/t counters) */
+    int bestAxis = -1; uint32_t bestSplit = count / 2; float bestCost = 1e30f;
+    float* rarea = (float*)malloc(count * sizeof(float));
+    for (int axis = 0; axis < 3; axis++) {
+        if (!(cmx[axis] - cmn[axis] > 0.0f)) continue;
+        g_axis = axis; g_cent = cent;
+        qsort(c->triOrder + first, count, sizeof(uint32_t), cmp_axis);
+        float bmn[3] = { 1e30f, 1e30f, 1e30f }, bmx[3] = { -1e30f, -1e30f, -1e30f };
+        for (uint32_t i = count; i-- > 1;) {
+            float a[3], b[3]; tri_bounds(&c->tris[c->triOrder[first + i]], a, b);
+            for (int k = 0; k < 3; k++) { bmn[k] = hrt_min(bmn[k], a[k]); bmx[k] = hrt_max(bmx[k], b[k]); }
+            float dx = bmx[0] - bmn[0], dy = bmx[1] - bmn[1], dz = bmx[2] - bmn[2];
+            rarea[i] = dx * dy + dy * dz + dz * dx;
+        }
+        bmn[0] = bmn[1] = bmn[2] = 1e30f; bmx[0] = bmx[1] = bmx[2] = -1e30f;
+        for (uint32_t i = 0; i + 1 < count; i++) {
+            float a[3], b[3]; tri_bounds(&c->tris[c->triOrder[first + i]], a, b);
+            for (int k = 0; k < 3; k++) { bmn[k] = hrt_min(bmn[k], a[k]); bmx[k] = hrt_max(bmx[k], b[k]); }
+            float dx = bmx[0] - bmn[0], dy = bmx[1] - bmn[1], dz = bmx[2] - bmn[2];
+            float cost = (dx * dy + dy * dz + dz * dx) * (float)(i + 1) + rarea[i + 1] * (float)(count - i - 1);
+            if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestSplit = i + 1; }
+        }
+    }
+    free(rarea);
+    if (bestAxis < 0) { bestAxis = 0; bestSplit = count / 2; }
+    g_axis = bestAxis; g_cent = cent;
     qsort(c->triOrder + first, count, sizeof(uint32_t), cmp_axis);
-    uint32_t half = count / 2;
+    uint32_t half = bestSplit;
     int32_t l = build_node(c, cent, first, half);
     int32_t r = build_node(c, cent, first + half, count - half);
     n = &c->nodes[id];
@@ -340,31 +362,44 @@ static Hit closest_any(const OrContext* c, const Ray* r, int haveLower, float lt
         for (uint32_t i = 0; i < c->triCount; i++) { tc->tris++; consider(c, i, r, &s, haveLower, lt, linst, lprim, &best); }
         return best;
     }
-    int32_t stack[96]; int sp = 0; stack[sp++] = 0;
+    /* Ordered traversal: a node is pushed only after its own box was hit; n counts AABB tests
+     * (one AABB 24 B + 8 B link each -- the traffic any BVH2 traversal must do). */
+    struct { int32_t node; float tnear; } stack[128]; int sp = 0;
     const float* o = &r->o.x; const float* d = &r->d.x;
     float inv[3]; for (int k = 0; k < 3; k++) inv[k] = 1.0f / d[k];
+    #define OR_BOX_TEST(NODE, TLIM, HIT, TNEAR) do { \
+        const BNode* bn_ = (NODE); float t0_ = r->tmin, t1_ = (TLIM); int miss_ = 0; tc->nodes++; \
+        for (int k = 0; k < 3 && !miss_; k++) { \
+            if (d[k] == 0.0f) { if (o[k] < bn_->bmin[k] || o[k] > bn_->bmax[k]) miss_ = 1; continue; } \
+            float ta_ = (bn_->bmin[k] - o[k]) * inv[k], tb_ = (bn_->bmax[k] - o[k]) * inv[k]; \
+            float lo_ = hrt_min(ta_, tb_), hi_ = hrt_max(ta_, tb_); \
+            lo_ = lo_ - hrt_abs(lo_) * 1e-6f; hi_ = hi_ + hrt_abs(hi_) * 1e-6f; \
+            t0_ = hrt_max(t0_, lo_); t1_ = hrt_min(t1_, hi_); if (t0_ > t1_) miss_ = 1; } \
+        (HIT) = !miss_; (TNEAR) = t0_; } while (0)
+    int rootHit; float rootNear;
+    OR_BOX_TEST(&c->nodes[0], r->tmax, rootHit, rootNear);
+    if (rootHit) { stack[sp].node = 0; stack[sp].tnear = rootNear; sp++; }
     while (sp) {
-        const BNode* n = &c->nodes[stack[--sp]];
-        tc->nodes++;
-        /* conservative slab test against [tmin, min(tmax, best.t)] */
-        float t0 = r->tmin, t1 = best.valid ? best.t : r->tmax;
-        int miss = 0;
-        for (int k = 0; k < 3 && !miss; k++) {
-            if (d[k] == 0.0f) { if (o[k] < n->bmin[k] || o[k] > n->bmax[k]) miss = 1; continue; }
-            float ta = (n->bmin[k] - o[k]) * inv[k], tb = (n->bmax[k] - o[k]) * inv[k];
-            float lo = hrt_min(ta, tb), hi = hrt_max(ta, tb);
-            lo = lo - hrt_abs(lo) * 1e-6f; hi = hi + hrt_abs(hi) * 1e-6f;
-            t0 = hrt_max(t0, lo); t1 = hrt_min(t1, hi);
-            if (t0 > t1) miss = 1;
-        }
-        if (miss) continue;
+        sp--;
+        const BNode* n = &c->nodes[stack[sp].node];
+        if (best.valid && stack[sp].tnear > best.t) continue;
         if (n->left < 0) {
             for (uint32_t i = n->first; i < n->first + n->count; i++) { tc->tris++; consider(c, c->triOrder[i], r, &s, haveLower, lt, linst, lprim, &best); }
         } else {
-            if (sp + 2 > 96) abort();
-            stack[sp++] = n->left; stack[sp++] = n->right;
+            float tlim = best.valid ? best.t : r->tmax;
+            int hl, hr; float tl, tr;
+            OR_BOX_TEST(&c->nodes[n->left], tlim, hl, tl);
+            OR_BOX_TEST(&c->nodes[n->right], tlim, hr, tr);
+            if (sp + 2 > 128) abort();
+            if (hl && hr) {
+                int leftFirst = tl <= tr;
+                stack[sp].node = leftFirst ? n->right : n->left; stack[sp].tnear = leftFirst ? tr : tl; sp++;
+                stack[sp].node = leftFirst ? n->left : n->right; stack[sp].tnear = leftFirst ? tl : tr; sp++;
+            } else if (hl) { stack[sp].node = n->left; stack[sp].tnear = tl; sp++; }
+            else if (hr) { stack[sp].node = n->right; stack[sp].tnear = tr; sp++; }
         }
     }
+    #undef OR_BOX_TEST
     return best;
 }
 

@@ -1,0 +1,64 @@
+"""CPU tests of the boundary: the C-ABI library loads without a GPU, exports every symbol include/hobbyrt_pt.h
+declares, fails loudly (no fallback) when no device exists, and the host-side BVH builder validates input."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hobbyrenderer_amd import native, scenes, structs as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "hobbyrt_pt.h")).read()
+    declared = set(re.findall(r"\b(hrpt_[a-z_]+)\s*\(", hdr))
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    for name in declared:
+        assert getattr(native.lib, name) is not None
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(S.SceneDesc) == 136 and C.sizeof(S.TextureDesc) == 16 and C.sizeof(S.DeviceDesc) == 8
+    assert S.FrameParams.itemsize == 768 + 6 * 4
+    assert C.sizeof(S.Stats) == 48
+
+
+def test_no_device_fails_loudly(gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(native.HrptError) as e:
+        native.PathTracerContext(0)
+    assert e.value.code == -2 and "no HIP device" in str(e.value)
+
+
+def test_invalid_arguments_return_codes():
+    h = C.c_void_p()
+    assert native.lib.hrpt_create(None, C.byref(h)) == -1
+    bad = S.DeviceDesc(0, 999)
+    assert native.lib.hrpt_create(C.byref(bad), C.byref(h)) == -1
+    assert native.lib.hrpt_render(None, None) == -1
+    assert native.lib.hrpt_resize(None, 4, 4) == -1
+    assert native.lib.hrpt_precompute_atmosphere(None, None, None, 1) == -1
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must not import / link / call anything under oracle/."""
+    pkg = os.path.join(ROOT, "hobbyrenderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() or f == "pt_megakernel.hip" and "CPU\n// oracle" in text or \
+                    all("oracle" not in ln.lower() or ln.lstrip().startswith(("//", "#", "*", '"')) for ln in text.splitlines()), (dirpath, f)
+
+
+def test_lut_precompute_is_deterministic_and_sane(luts):
+    t, s, i = luts
+    t2, s2, _ = native.precompute_atmosphere(3)
+    assert np.array_equal(t, t2) and np.array_equal(s, s2)
+    assert np.isfinite(t).all() and np.isfinite(s).all() and (t[..., :3] >= 0).all() and (t[..., :3] <= 1).all()
+    assert t[63, 0, 0] > 0.99 and 0.8 < t[0, 0, 0] < 0.99   # from the top / from the ground, looking straight up
+    assert (s >= 0).all() and s.max() < 10
