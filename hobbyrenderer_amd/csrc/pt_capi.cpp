@@ -33,7 +33,7 @@ struct HrptContext {
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
     WavefrontState wf;
-    float traceMs = 0.0f; uint32_t traceLaunches = 0;
+    SceneTraits traits;
 };
 
 static std::mutex g_errMutex;
@@ -195,6 +195,13 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
 
     c->view = v; c->haveScene = true;
     c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
+    c->traits = SceneTraits();
+    c->traits.bvhMaxDepth = bvh.maxDepth;
+    for (uint32_t i = 0; i < s->instanceCount; ++i) {
+        const HrptMaterialConstants& m = s->materials[s->instances[i].m_MaterialIndex];
+        if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;
+        if (m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND && !(m.m_TransmissionFactor > 0.0f)) c->traits.hasStochasticAlpha = true;
+    }
     return HRPT_OK;
 }
 
@@ -245,11 +252,10 @@ int hrpt_render(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipSetDevice(c->device));
 
     bool wavefront = (p->flags & HRPT_FRAME_MEGAKERNEL) == 0 && wavefront_supports(c->view, p->constants);
-    c->traceMs = 0.0f; c->traceLaunches = 0;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (wavefront) {
         std::string werr;
-        hipError_t e = wavefront_render(c->wf, c->view, p->constants, p->accumCount, c->dAccum, c->dOutput, c->width, c->height, rect,
+        hipError_t e = wavefront_render(c->wf, c->view, c->traits, p->constants, p->accumCount, c->dAccum, c->dOutput, c->width, c->height, rect,
                                         c->dCounters, c->stream, werr);
         if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? HRPT_ERR_OUT_OF_MEMORY : HRPT_ERR_HIP, "wavefront_render: " + werr + ": " + hipGetErrorString(e));
     } else {
@@ -334,7 +340,9 @@ int hrpt_reset_stats(HrptContext* c)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
+    wavefront_reset_timing(c->wf);
     return HRPT_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/hobbyrt_pt.h"
 #include "pt_kernels.h"
@@ -12,20 +13,32 @@ namespace hrt {
 
 struct SceneView;
 
+// Facts about the uploaded scene that select kernel variants / optional state streams.
+struct SceneTraits {
+    bool hasMedium = false;            // a thick (non-thin) transmissive material exists: interior IOR/sigma travel with the path
+    bool hasStochasticAlpha = false;   // a non-transmissive BLEND material exists: TraceRayStandard draws RNG (RaytracingCommon.hlsli:181)
+    uint32_t bvhMaxDepth = 0;
+};
+
 struct WavefrontState {
-    void* pool = nullptr;            // one device allocation carved into the SoA queues
+    void* pool = nullptr;              // one device allocation carved into the SoA queues
     size_t poolBytes = 0;
-    uint32_t capacityPaths = 0;
-    hipEvent_t evA = nullptr, evB = nullptr;
-    float traceMs = 0.0f;            // summed device time of the closest-hit trace kernel in the last render
+    std::vector<hipEvent_t> events;    // start/stop pairs around every closest-hit trace launch
+    uint32_t eventsUsed = 0;
+    float traceMs = 0.0f;              // summed device time of wf_extend since the last reset
     uint32_t traceLaunches = 0;
+    // tuning knobs (0 = default)
+    uint64_t maxSamplesPerBatch = 0;
+    uint32_t blocksPerCu = 0;
+    bool forceGlobalBvh = false;
 };
 
 bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& constants);
-hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const HrptPathTracerConstants& constants, uint32_t accumCount,
-                            float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
+hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptPathTracerConstants& constants,
+                            uint32_t accumCount, float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
                             DeviceCounters* counters, hipStream_t stream, std::string& error);
 void wavefront_release(WavefrontState& st);
-void wavefront_trace_timing(const WavefrontState& st, float* ms, uint32_t* launches);
+void wavefront_trace_timing(WavefrontState& st, float* ms, uint32_t* launches);   // call after the stream is synchronised
+void wavefront_reset_timing(WavefrontState& st);
 
 } // namespace hrt

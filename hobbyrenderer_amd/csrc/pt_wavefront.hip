@@ -1,10 +1,518 @@
-// pt_wavefront.hip -- placeholder until the wavefront pipeline lands (next commit).
+// pt_wavefront.hip -- the production path: a persistent-threads wavefront path tracer for gfx950.
+//
+// One hrpt_render = all requested accumulation indices ("spp") of a tile at once:
+//   wf_raygen -> per bounce { wf_extend -> wf_shade -> wf_shadow } -> wf_resolve
+// replacing the single PathTracer_CSMain dispatch per index of the reference
+// (/root/reference/src/shaders/PathTracer.hlsl:53-340, src/PathTracerRenderer.cpp:96-103).
+//
+// Data layout in HBM (one pool, SoA of float4, all streams coalesced 16 B/lane):
+//   path queues A/B (ping-pong per bounce): rayO{o.xyz,tmin} rayD{d.xyz,rng} thr{T.xyz,sample} [med0{sigmaA,ior} med1{sigmaS,inVolume}]
+//   hit records of the current queue:       hitA{t,u,v,prim} hitI{inst}
+//   shadow queue:                           sh0{origin,sample} sh1{T,count} + per light sample shL{L,maxDist} shD{diffuse} shS{specular}
+//   sampleRadiance[sample] (rgb): one slot per (pixel, accumulation index); emissive / NEE / sky are added in path order,
+//                                 wf_resolve then folds the indices in order exactly like progressive accumulation (:332-339).
+// Queues are SEGMENTED: a segment is 1024 consecutive samples owned by ONE wave at a time. The owning wave
+// compacts survivors inside its segment with __ballot + popcount prefix (no global atomics, no block barriers,
+// deterministic layout, pixel tiles stay together), and writes the segment's live count. Every kernel is a fixed
+// grid of persistent waves striding over segments; each wave reaches its exit when the segment index runs out.
+// The BVH (nodes + world-space triangles) is copied to LDS when it fits, and the traversal stack lives in LDS,
+// one column per lane (conflict-free), sized from the builder's maximum depth.
 #include "pt_wavefront.h"
-#include "pt_device.h"
+
+#include <vector>
+
+#include "bvh_build.h"
+#include "pt_path.h"
+
 namespace hrt {
-bool wavefront_supports(const SceneView&, const HrptPathTracerConstants&) { return false; }
-hipError_t wavefront_render(WavefrontState&, const SceneView&, const HrptPathTracerConstants&, uint32_t, float4*, float4*, uint32_t, uint32_t,
-                            TileRect, DeviceCounters*, hipStream_t, std::string& error) { error = "not built"; return hipErrorNotSupported; }
-void wavefront_release(WavefrontState&) {}
-void wavefront_trace_timing(const WavefrontState& st, float* ms, uint32_t* n) { *ms = st.traceMs; *n = st.traceLaunches; }
+
+namespace {
+
+constexpr uint32_t kSegment = 1024;          // samples per wave-owned segment
+constexpr uint32_t kBlock = 256;             // 4 waves
+constexpr uint32_t kMaxLights = 8;
+constexpr uint32_t kMaxSppPerBatch = 64;
+constexpr size_t kLdsBudget = 64 * 1024;     // dynamic LDS per block: traversal stacks + BVH copy
+
+struct WfBuffers {
+    float4 *rayO[2], *rayD[2], *thr[2], *med0[2], *med1[2];
+    uint32_t* pathCnt[2];
+    float4* hitA; uint32_t* hitI;
+    float4 *sh0, *sh1, *shL, *shD, *shS;
+    uint32_t* shadowCnt;
+    float4* radiance;
+};
+
+struct WfArgs {
+    SceneView scene;
+    WfBuffers b;
+    uint32_t numSegments;      // segments in this batch
+    uint32_t numSamples;       // tilesX*tilesY*64*spp (padded to 8x8 pixel tiles)
+    uint32_t pixelsPadded;     // tilesX*tilesY*64
+    uint32_t tilesX, tilesY;
+    TileRect rect;
+    uint32_t imageWidth;
+    uint32_t spp;              // accumulation indices in this batch
+    uint32_t maxLights;        // per-path light-sample slots in the shadow queue
+    uint32_t hasMedium;        // scene has thick transmissive materials (medium state travels with the path)
+    uint32_t hasStochasticAlpha;
+    DeviceCounters* counters;
+};
+
+struct JitterTable { float2 j[kMaxSppPerBatch]; };
+
+// per-lane traversal stack in LDS: element (sp, lane-in-block) at base[sp * kBlock]
+template <int DEPTH>
+struct LdsStack {
+    int32_t* base;
+    HRT_DEV void push(int sp, int32_t v) { base[(sp & (DEPTH - 1)) * kBlock] = v; }
+    HRT_DEV int32_t pop(int sp) { return base[(sp & (DEPTH - 1)) * kBlock]; }
+};
+struct LdsBvh {
+    const float4* nodes; const float4* tris;
+    HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+    HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
+};
+
+// Carves dynamic LDS: [stack: DEPTH*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
+template <bool LDS_BVH, int DEPTH>
+HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh& lbvh)
+{
+    stack.base = reinterpret_cast<int32_t*>(smem) + threadIdx.x;
+    if (LDS_BVH) {
+        float4* dst = reinterpret_cast<float4*>(smem + (size_t)DEPTH * kBlock * 4);
+        const float4* srcN = reinterpret_cast<const float4*>(s.nodes);
+        const float4* srcT = reinterpret_cast<const float4*>(s.tris);
+        uint32_t nN = s.nodeCount * 4, nT = s.triCount * 3;
+        for (uint32_t i = threadIdx.x; i < nN; i += kBlock) dst[i] = srcN[i];
+        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) dst[nN + i] = srcT[i];
+        lbvh.nodes = dst; lbvh.tris = dst + nN;
+        __syncthreads();
+    }
 }
+
+HRT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+HRT_DEV uint32_t prefix_rank(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+
+HRT_DEV unsigned long long wave_sum_u32(unsigned int v)
+{
+    unsigned long long x = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// ------------------------------------------------------------------ raygen
+__global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerConstants cb, JitterTable jt)
+{
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    unsigned int nPaths = 0;
+    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+        uint32_t segBase = seg * kSegment, outCount = 0;
+        for (uint32_t base = 0; base < kSegment; base += 64) {
+            uint32_t smp = segBase + base + lane;
+            bool active = smp < a.numSamples;
+            uint32_t k = 0, px = 0, py = 0;
+            if (active) {
+                k = smp / a.pixelsPadded;
+                uint32_t p = smp - k * a.pixelsPadded;
+                uint32_t tile = p >> 6, within = p & 63u;
+                px = a.rect.x0 + (tile % a.tilesX) * 8u + (within & 7u);
+                py = a.rect.y0 + (tile / a.tilesX) * 8u + (within >> 3);
+                active = px < a.rect.x1 && py < a.rect.y1;
+            }
+            if (smp < a.numSamples) a.b.radiance[smp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            unsigned long long m = __ballot(active);
+            if (active) {
+                PathState ps;
+                {
+                    // init_path (pt_path.h) with the jitter / RNG stream of accumulation index first+k (PathTracerRenderer.cpp:62,:65)
+                    float u = (((float)px + 0.5f) + jt.j[k].x) * cb.m_View.m_ViewportSizeInv[0];
+                    float v = (((float)py + 0.5f) + jt.j[k].y) * cb.m_View.m_ViewportSizeInv[1];
+                    float cx = u * 2.0f + -1.0f, cy = v * -2.0f + 1.0f;
+                    const float* M = cb.m_View.m_MatClipToWorldNoOffset;
+                    float ex = ((cx * M[0] + cy * M[4]) + 0.9f * M[8]) + 1.0f * M[12];
+                    float ey = ((cx * M[1] + cy * M[5]) + 0.9f * M[9]) + 1.0f * M[13];
+                    float ez = ((cx * M[2] + cy * M[6]) + 0.9f * M[10]) + 1.0f * M[14];
+                    float ew = ((cx * M[3] + cy * M[7]) + 0.9f * M[11]) + 1.0f * M[15];
+                    f3 end = mk3(ex / ew, ey / ew, ez / ew);
+                    ps.ray.o = mk3(cb.m_CameraPos[0], cb.m_CameraPos[1], cb.m_CameraPos[2]);
+                    ps.ray.d = normalize(end - ps.ray.o);
+                    ps.rng = hrt_rng_seed(px, py, cb.m_AccumulationIndex + k);
+                }
+                uint32_t o = segBase + outCount + prefix_rank(m);
+                a.b.rayO[0][o] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, 0.0f);
+                a.b.rayD[0][o] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.rng));
+                a.b.thr[0][o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(smp));
+                if (a.hasMedium) {
+                    a.b.med0[0][o] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                    a.b.med1[0][o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                ++nPaths;
+            }
+            outCount += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) a.b.pathCnt[0][seg] = outCount;
+    }
+    unsigned long long np = wave_sum_u32(nPaths);
+    if (lane == 0 && np) atomicAdd(&a.counters->paths, np);
+}
+
+// ------------------------------------------------------------------ extend (closest hit)
+template <bool LDS_BVH, int DEPTH>
+__global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStack<DEPTH> stack; LdsBvh lbvh;
+    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
+    GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const float4* __restrict__ rayO = a.b.rayO[parity];
+    float4* __restrict__ rayD = a.b.rayD[parity];
+    unsigned int nRays = 0;
+    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+        const uint32_t cnt = a.b.pathCnt[parity][seg], segBase = seg * kSegment;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            uint32_t i = base + lane;
+            if (i < cnt) {
+                uint32_t slot = segBase + i;
+                float4 o = rayO[slot], d = rayD[slot];
+                Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = 1e10f;
+                uint32_t rng = __float_as_uint(d.w), rng0 = rng;
+                Hit h; bool hit;
+                if (LDS_BVH) hit = trace_standard(a.scene, lbvh, r, rng, stack, h);
+                else hit = trace_standard(a.scene, gbvh, r, rng, stack, h);
+                if (a.hasStochasticAlpha && rng != rng0) { d.w = __uint_as_float(rng); rayD[slot] = d; }
+                a.b.hitA[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+                a.b.hitI[slot] = hit ? h.inst : 0xFFFFFFFFu;
+                ++nRays;
+            }
+        }
+    }
+    unsigned long long nr = wave_sum_u32(nRays);
+    if (lane == 0 && nr) atomicAdd(&a.counters->closestRays, nr);
+}
+
+// ------------------------------------------------------------------ shade (+ compaction, + NEE sample emission)
+template <int MAXL>
+struct NeeBuf { f3 L[MAXL]; float maxDist[MAXL]; f3 dif[MAXL], spec[MAXL]; };
+
+template <int MAXL>
+__global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+{
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t in = parity, out = parity ^ 1u;
+    const SceneView& s = a.scene;
+    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+        const uint32_t cnt = a.b.pathCnt[in][seg], segBase = seg * kSegment;
+        uint32_t outCount = 0, shCount = 0;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            uint32_t i = base + lane;
+            bool valid = i < cnt, alive = false;
+            uint32_t nNee = 0, smp = 0;
+            PathState ps; f3 worldPos = mk3(0.0f, 0.0f, 0.0f), neeT = mk3(0.0f, 0.0f, 0.0f);
+            NeeBuf<MAXL> nee;
+            if (valid) {
+                uint32_t slot = segBase + i;
+                float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
+                float4 ha = a.b.hitA[slot]; uint32_t inst = a.b.hitI[slot];
+                ps.ray.o = mk3(o.x, o.y, o.z); ps.ray.d = mk3(d.x, d.y, d.z); ps.ray.tmin = o.w; ps.ray.tmax = 1e10f;
+                ps.rng = __float_as_uint(d.w);
+                ps.throughput = mk3(t.x, t.y, t.z); smp = __float_as_uint(t.w);
+                ps.radiance = mk3(0.0f, 0.0f, 0.0f);   // contributions of THIS stage; added to sampleRadiance below
+                if (a.hasMedium) {
+                    float4 m0 = a.b.med0[in][slot], m1 = a.b.med1[in][slot];
+                    ps.sigmaA = mk3(m0.x, m0.y, m0.z); ps.interiorIOR = m0.w; ps.sigmaS = mk3(m1.x, m1.y, m1.z); ps.inVolume = m1.w != 0.0f;
+                } else { ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); ps.interiorIOR = 1.0f; ps.inVolume = false; }
+                bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
+                if (inst != 0xFFFFFFFFu) {
+                    Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.prim = __float_as_uint(ha.w); h.inst = inst; h.opaque = 1;
+                    SurfaceCarry carry;
+                    f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
+                    SurfaceOutcome oc = shade_surface_a(s, cb, ps, h, carry, [&](uint32_t, f3 wp, f3 L, float maxDist, f3 dif, f3 spec) {
+                        if (nNee < (uint32_t)MAXL) {
+                            worldPos = wp;
+                            nee.L[nNee] = L; nee.maxDist[nNee] = maxDist; nee.dif[nNee] = dif; nee.spec[nNee] = spec;
+                            ++nNee;
+                        }
+                    });
+                    if (oc == SURFACE_TRANSMITTED) alive = true;
+                    else {
+                        // ps.radiance now holds throughput*emissive of this hit (PathTracer.hlsl:258)
+                        emissiveTerm = ps.radiance;
+                        if (emissiveTerm.x != 0.0f || emissiveTerm.y != 0.0f || emissiveTerm.z != 0.0f) { addRadiance = true; add = emissiveTerm; }
+                        neeT = ps.throughput;
+                        alive = shade_surface_b(ps, carry, bounce);
+                    }
+                } else {
+                    miss_sky(s, cb, ps, bounce);   // ps.radiance = throughput * sky
+                    addRadiance = true; add = ps.radiance;
+                }
+                if (addRadiance) {
+                    // radiance_total = radiance_total + term, in path order (x + 0 == x, so zero terms are skipped)
+                    float4 r = a.b.radiance[smp];
+                    r.x = r.x + add.x; r.y = r.y + add.y; r.z = r.z + add.z;
+                    a.b.radiance[smp] = r;
+                }
+                if (lastBounce) alive = false;
+            }
+            // ---- wave-local compaction of survivors into the out queue
+            unsigned long long m = __ballot(alive);
+            if (alive) {
+                uint32_t o = segBase + outCount + prefix_rank(m);
+                a.b.rayO[out][o] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tmin);
+                a.b.rayD[out][o] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.rng));
+                a.b.thr[out][o] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, __uint_as_float(smp));
+                if (a.hasMedium) {
+                    a.b.med0[out][o] = make_float4(ps.sigmaA.x, ps.sigmaA.y, ps.sigmaA.z, ps.interiorIOR);
+                    a.b.med1[out][o] = make_float4(ps.sigmaS.x, ps.sigmaS.y, ps.sigmaS.z, ps.inVolume ? 1.0f : 0.0f);
+                }
+            }
+            outCount += (uint32_t)__popcll(m);
+            // ---- wave-local compaction of NEE work into the shadow queue
+            unsigned long long ms = __ballot(nNee > 0);
+            if (nNee > 0) {
+                uint32_t e = segBase + shCount + prefix_rank(ms);
+                a.b.sh0[e] = make_float4(worldPos.x, worldPos.y, worldPos.z, __uint_as_float(smp));
+                a.b.sh1[e] = make_float4(neeT.x, neeT.y, neeT.z, __uint_as_float(nNee));
+#pragma unroll
+                for (int j = 0; j < MAXL; ++j) {
+                    if ((uint32_t)j < nNee) {
+                        size_t q = (size_t)e * a.maxLights + j;
+                        a.b.shL[q] = make_float4(nee.L[j].x, nee.L[j].y, nee.L[j].z, nee.maxDist[j]);
+                        a.b.shD[q] = make_float4(nee.dif[j].x, nee.dif[j].y, nee.dif[j].z, 0.0f);
+                        if (bounce == 0) a.b.shS[q] = make_float4(nee.spec[j].x, nee.spec[j].y, nee.spec[j].z, 0.0f);
+                    }
+                }
+            }
+            shCount += (uint32_t)__popcll(ms);
+        }
+        if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
+    }
+}
+
+// ------------------------------------------------------------------ shadow (NEE visibility + accumulation)
+template <bool LDS_BVH, int DEPTH>
+__global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStack<DEPTH> stack; LdsBvh lbvh;
+    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
+    GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    unsigned int nRays = 0;
+    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg * kSegment;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            uint32_t i = base + lane;
+            if (i < cnt) {
+                uint32_t e = segBase + i;
+                float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e];
+                f3 origin = mk3(h0.x, h0.y, h0.z), T = mk3(h1.x, h1.y, h1.z);
+                uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h1.w);
+                f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
+                for (uint32_t j = 0; j < n; ++j) {
+                    size_t q = (size_t)e * a.maxLights + j;
+                    float4 l = a.b.shL[q];
+                    float shadow;
+                    if (LDS_BVH) shadow = shadow_query(a.scene, lbvh, origin, mk3(l.x, l.y, l.z), l.w, stack);
+                    else shadow = shadow_query(a.scene, gbvh, origin, mk3(l.x, l.y, l.z), l.w, stack);
+                    ++nRays;
+                    if (shadow != 0.0f) {   // (x*0) contributes +0: skipped, sums are unchanged
+                        float4 dd = a.b.shD[q];
+                        totalDiffuse = totalDiffuse + mk3(dd.x, dd.y, dd.z) * shadow;
+                        if (bounce == 0) { float4 ss = a.b.shS[q]; totalSpecular = totalSpecular + mk3(ss.x, ss.y, ss.z) * shadow; }
+                    }
+                }
+                f3 dsum = totalDiffuse + (bounce == 0 ? totalSpecular : mk3(0.0f, 0.0f, 0.0f));
+                if (dsum.x != 0.0f || dsum.y != 0.0f || dsum.z != 0.0f) {
+                    f3 term = T * dsum;                                         // PathTracer.hlsl:261
+                    float4 r = a.b.radiance[smp];
+                    r.x = r.x + term.x; r.y = r.y + term.y; r.z = r.z + term.z;
+                    a.b.radiance[smp] = r;
+                }
+            }
+        }
+    }
+    unsigned long long nr = wave_sum_u32(nRays);
+    if (lane == 0 && nr) atomicAdd(&a.counters->shadowRays, nr);
+}
+
+// ------------------------------------------------------------------ resolve: fold the indices in order (:332-339)
+__global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restrict__ accumulation, float4* __restrict__ output, uint32_t firstIndex)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (; p < a.pixelsPadded; p += stride) {
+        uint32_t tile = p >> 6, within = p & 63u;
+        uint32_t px = a.rect.x0 + (tile % a.tilesX) * 8u + (within & 7u), py = a.rect.y0 + (tile / a.tilesX) * 8u + (within >> 3);
+        if (px >= a.rect.x1 || py >= a.rect.y1) continue;
+        size_t idx = (size_t)py * a.imageWidth + px;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < a.spp; ++k) {
+            float4 r = a.b.radiance[(size_t)k * a.pixelsPadded + p];
+            float4 cur = make_float4(r.x, r.y, r.z, 1.0f);
+            if (firstIndex + k > 0) {
+                float4 prev = (k == 0) ? accumulation[idx] : acc;
+                cur.x += prev.x; cur.y += prev.y; cur.z += prev.z; cur.w += prev.w;
+            }
+            acc = cur;
+        }
+        accumulation[idx] = acc;
+        output[idx] = make_float4(acc.x / acc.w, acc.y / acc.w, acc.z / acc.w, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct Variant { bool lds; int depth; };
+
+template <bool L, int D> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D>), g, dim3(kBlock), sh, st, a, parity); }
+template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, int bounce) { hipLaunchKernelGGL((wf_shadow<L, D>), g, dim3(kBlock), sh, st, a, bounce); }
+
+void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
+{
+    if (v.lds) { if (v.depth <= 8) launch_extend_t<true, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<true, 16>(g, sh, st, a, parity); else launch_extend_t<true, 32>(g, sh, st, a, parity); }
+    else { if (v.depth <= 8) launch_extend_t<false, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<false, 16>(g, sh, st, a, parity); else launch_extend_t<false, 32>(g, sh, st, a, parity); }
+}
+void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, int bounce)
+{
+    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, bounce); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, bounce); else launch_shadow_t<true, 32>(g, sh, st, a, bounce); }
+    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, bounce); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, bounce); else launch_shadow_t<false, 32>(g, sh, st, a, bounce); }
+}
+
+} // namespace
+
+bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& cb)
+{
+    (void)scene;
+    return cb.m_LightCount <= kMaxLights && cb.m_MaxBounces >= 1;
+}
+
+void wavefront_release(WavefrontState& st)
+{
+    if (st.pool) (void)hipFree(st.pool);
+    st.pool = nullptr; st.poolBytes = 0;
+    for (hipEvent_t e : st.events) (void)hipEventDestroy(e);
+    st.events.clear(); st.eventsUsed = 0;
+}
+
+void wavefront_trace_timing(WavefrontState& st, float* ms, uint32_t* launches)
+{
+    // called after the stream has been synchronised
+    if (st.eventsUsed) {
+        float total = 0.0f;
+        for (uint32_t i = 0; i + 1 < st.eventsUsed; i += 2) { float t = 0.0f; if (hipEventElapsedTime(&t, st.events[i], st.events[i + 1]) == hipSuccess) total += t; }
+        st.traceMs += total; st.traceLaunches += st.eventsUsed / 2; st.eventsUsed = 0;
+    }
+    *ms = st.traceMs; *launches = st.traceLaunches;
+}
+
+void wavefront_reset_timing(WavefrontState& st) { st.traceMs = 0.0f; st.traceLaunches = 0; st.eventsUsed = 0; }
+
+hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptPathTracerConstants& constants,
+                            uint32_t accumCount, float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
+                            DeviceCounters* counters, hipStream_t stream, std::string& error)
+{
+    (void)height;
+    if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0) return hipSuccess;
+    hipError_t e;
+    const uint32_t tilesX = (rect.x1 - rect.x0 + 7) / 8, tilesY = (rect.y1 - rect.y0 + 7) / 8;
+    const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64;
+    // batch the accumulation indices so that one batch stays below maxSamples
+    uint32_t sppPerBatch = accumCount < kMaxSppPerBatch ? accumCount : kMaxSppPerBatch;
+    const uint64_t maxSamples = st.maxSamplesPerBatch ? st.maxSamplesPerBatch : (64ull << 20);
+    while (sppPerBatch > 1 && pixelsPadded * sppPerBatch > maxSamples) --sppPerBatch;
+    const uint64_t capacity = ((pixelsPadded * sppPerBatch + kSegment - 1) / kSegment) * kSegment;
+    if (capacity >= (1ull << 31)) { error = "tile too large for one batch"; return hipErrorInvalidValue; }
+    const uint32_t maxLights = constants.m_LightCount ? constants.m_LightCount : 1;
+    const uint32_t segs = (uint32_t)(capacity / kSegment);
+
+    // ---- pool layout
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oRayO[2], oRayD[2], oThr[2], oMed0[2] = { 0, 0 }, oMed1[2] = { 0, 0 }, oCnt[2];
+    for (int p = 0; p < 2; ++p) {
+        oRayO[p] = carve(capacity * 16); oRayD[p] = carve(capacity * 16); oThr[p] = carve(capacity * 16);
+        if (traits.hasMedium) { oMed0[p] = carve(capacity * 16); oMed1[p] = carve(capacity * 16); }
+        oCnt[p] = carve((size_t)segs * 4);
+    }
+    size_t oHitA = carve(capacity * 16), oHitI = carve(capacity * 4);
+    size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16);
+    size_t oShL = carve(capacity * 16 * maxLights), oShD = carve(capacity * 16 * maxLights), oShS = carve(capacity * 16 * maxLights);
+    size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
+    if (off > st.poolBytes) {
+        if (st.pool) { (void)hipStreamSynchronize(stream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
+        e = hipMalloc(&st.pool, off);
+        if (e != hipSuccess) { error = "hipMalloc(queue pool)"; return e; }
+        st.poolBytes = off;
+    }
+    char* base = static_cast<char*>(st.pool);
+    WfArgs a{};
+    a.scene = scene;
+    for (int p = 0; p < 2; ++p) {
+        a.b.rayO[p] = (float4*)(base + oRayO[p]); a.b.rayD[p] = (float4*)(base + oRayD[p]); a.b.thr[p] = (float4*)(base + oThr[p]);
+        a.b.med0[p] = (float4*)(base + oMed0[p]); a.b.med1[p] = (float4*)(base + oMed1[p]); a.b.pathCnt[p] = (uint32_t*)(base + oCnt[p]);
+    }
+    a.b.hitA = (float4*)(base + oHitA); a.b.hitI = (uint32_t*)(base + oHitI);
+    a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1);
+    a.b.shL = (float4*)(base + oShL); a.b.shD = (float4*)(base + oShD); a.b.shS = (float4*)(base + oShS);
+    a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
+    a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
+    a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
+    a.counters = counters;
+
+    // ---- kernel variants and grids
+    int dev = 0; hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    Variant v;
+    v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : 32);
+    const size_t bvhBytes = (size_t)scene.nodeCount * 64 + (size_t)scene.triCount * 48;
+    const size_t stackBytes = (size_t)v.depth * kBlock * 4;
+    v.lds = bvhBytes > 0 && stackBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
+    const size_t traceLds = stackBytes + (v.lds ? bvhBytes : 0);
+    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 8;
+
+    const bool manyLights = maxLights > 1;
+    for (uint32_t first = 0; first < accumCount; first += sppPerBatch) {
+        const uint32_t spp = (accumCount - first) < sppPerBatch ? (accumCount - first) : sppPerBatch;
+        a.spp = spp; a.numSamples = (uint32_t)(pixelsPadded * spp);
+        a.numSegments = (a.numSamples + kSegment - 1) / kSegment;
+        const uint32_t wavesNeeded = a.numSegments, blocksNeeded = (wavesNeeded + 3) / 4;
+        uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = blocksNeeded; if (grid == 0) grid = 1;
+
+        HrptPathTracerConstants cb = constants;
+        cb.m_AccumulationIndex = constants.m_AccumulationIndex + first;
+        JitterTable jt;
+        for (uint32_t k = 0; k < spp; ++k) {   // PathTracerRenderer.cpp:65
+            jt.j[k].x = hrpt_halton(cb.m_AccumulationIndex + k + 1, 2) - 0.5f;
+            jt.j[k].y = hrpt_halton(cb.m_AccumulationIndex + k + 1, 3) - 0.5f;
+        }
+        hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
+        const int maxBounces = (int)cb.m_MaxBounces;
+        for (int bounce = 0; bounce < maxBounces; ++bounce) {
+            const uint32_t parity = (uint32_t)bounce & 1u;
+            if (st.eventsUsed + 2 > st.events.size()) { hipEvent_t e0, e1; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { error = "hipEventCreate"; return hipErrorOutOfMemory; } st.events.push_back(e0); st.events.push_back(e1); }
+            (void)hipEventRecord(st.events[st.eventsUsed], stream);
+            launch_extend(v, dim3(grid), traceLds, stream, a, parity);
+            (void)hipEventRecord(st.events[st.eventsUsed + 1], stream);
+            st.eventsUsed += 2;
+            const int last = bounce + 1 == maxBounces ? 1 : 0;
+            if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else hipLaunchKernelGGL((wf_shade<1>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            launch_shadow(v, dim3(grid), traceLds, stream, a, bounce);
+        }
+        uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;
+        hipLaunchKernelGGL(wf_resolve, dim3(rgrid), dim3(kBlock), 0, stream, a, accumulation, output, cb.m_AccumulationIndex);
+        if ((e = hipGetLastError()) != hipSuccess) { error = "kernel launch"; return e; }
+    }
+    return hipSuccess;
+}
+
+} // namespace hrt
