@@ -151,62 +151,61 @@ struct GlobalBvh {
     }
 };
 
-// Conservative slab test of one child box against [t0, t1]; returns entry distance or -1.
-HRT_DEV bool slab(const float* bmin, const float* bmax, const Ray& r, f3 inv, float t0, float t1, float& tnear)
+// Conservative slab test of one child box against [t0, t1]. Culling only: it never changes which hit is
+// reported (the hit definition is BVH-independent), so it may use native min/max, the hardware reciprocal and
+// FMA. A NaN plane distance (zero direction component with the origin exactly on a padded slab plane) culls the
+// box, which is still conservative: padded planes lie strictly outside every triangle extent inside the box.
+HRT_DEV bool slab(float4 bmin, float4 bmax, f3 o, f3 inv, float t0, float t1, float& tnear)
 {
-    float lo0 = t0, hi0 = t1;
-    const float o[3] = { r.o.x, r.o.y, r.o.z };
-    const float d[3] = { r.d.x, r.d.y, r.d.z };
-    const float iv[3] = { inv.x, inv.y, inv.z };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (d[k] == 0.0f) {
-            if (o[k] < bmin[k] || o[k] > bmax[k]) return false;
-        } else {
-            float ta = (bmin[k] - o[k]) * iv[k], tb = (bmax[k] - o[k]) * iv[k];
-            float lo = hrt_min(ta, tb), hi = hrt_max(ta, tb);
-            lo = lo - hrt_abs(lo) * 1e-6f; hi = hi + hrt_abs(hi) * 1e-6f;
-            lo0 = hrt_max(lo0, lo); hi0 = hrt_min(hi0, hi);
-        }
-    }
-    tnear = lo0;
-    return lo0 <= hi0;
+    float tx0 = (bmin.x - o.x) * inv.x, tx1 = (bmax.x - o.x) * inv.x;
+    float ty0 = (bmin.y - o.y) * inv.y, ty1 = (bmax.y - o.y) * inv.y;
+    float tz0 = (bmin.z - o.z) * inv.z, tz1 = (bmax.z - o.z) * inv.z;
+    float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), t0));
+    float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fminf(__builtin_fmaxf(tz0, tz1), t1));
+    tnear = lo;
+    // widen by 2e-6 relative for the rounding of the plane distances
+    return __builtin_fmaf(-__builtin_fabsf(lo), 2e-6f, lo) <= __builtin_fmaf(__builtin_fabsf(hi), 2e-6f, hi);
 }
 
-struct TravStats { uint32_t nodes, tris; };
+constexpr int32_t kTraversalDone = (int32_t)0x80000000;   // not a valid leaf encoding (first < 2^29)
 
-// Closest triangle (opaque or not) with key strictly above `lower` (when lower.have) in
-// (t, inst, prim) order. STACK: per-lane traversal stack accessor (LDS or private).
+HRT_DEV f3 traversal_rcp(f3 d)
+{
+    return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+}
+
+// Closest triangle (opaque or not) with key strictly above `lower` (when lower.have) in (t, inst, prim) order.
+// while-while traversal: all lanes of the wave first descend inner nodes, then intersect leaves together.
+// STACK: per-lane traversal stack accessor (LDS column or private array).
 template <class BVH, class STACK>
 HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack)
 {
     Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
     RayShear sh = make_shear(r.d);
-    f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    f3 inv = traversal_rcp(r.d);
     int sp = 0;
     int32_t cur;                       // current node reference: >= 0 inner, < 0 leaf
     if (nodeCount == 0) { if (rootLeaf == 0) return best; cur = rootLeaf; }
     else cur = 0;
+    float tlim = r.tmax;               // == best.t once a hit exists
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             float4 a, b, c, d; bvh.node(cur, a, b, c, d);
-            float lmin[3] = { a.x, a.y, a.z }, lmax[3] = { b.x, b.y, b.z };
-            float rmin[3] = { c.x, c.y, c.z }, rmax[3] = { d.x, d.y, d.z };
             int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
             float tl, tr;
-            float tlim = best.valid ? best.t : r.tmax;
-            bool hl = slab(lmin, lmax, r, inv, r.tmin, tlim, tl);
-            bool hr = slab(rmin, rmax, r, inv, r.tmin, tlim, tr);
+            bool hl = slab(a, b, r.o, inv, r.tmin, tlim, tl);
+            bool hr = slab(c, d, r.o, inv, r.tmin, tlim, tr);
             if (hl && hr) {
                 bool leftFirst = tl <= tr;
-                int32_t nearI = leftFirst ? li : ri, farI = leftFirst ? ri : li;
-                stack.push(sp++, farI);
-                cur = nearI;
-                continue;
-            } else if (hl) { cur = li; continue; }
-            else if (hr) { cur = ri; continue; }
-        } else {
+                stack.push(sp++, leftFirst ? ri : li);
+                cur = leftFirst ? li : ri;
+            } else if (hl) cur = li;
+            else if (hr) cur = ri;
+            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+        }
+        if (cur == kTraversalDone) break;
+        {
             uint32_t enc = (uint32_t)(~cur);
             uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
@@ -218,6 +217,7 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
                     if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
                         best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
                         best.opaque = __float_as_uint(c.w) & 1u;
+                        tlim = t;
                     }
                 }
             }
@@ -228,30 +228,31 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     return best;
 }
 
-// Any opaque-instance triangle in (tmin, tmax)? Early exit. Non-opaque triangles are ignored.
+// Any opaque-instance triangle in (tmin, tmax)? Early exit. Non-opaque triangles are only noted.
 template <class BVH, class STACK>
 HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, bool& sawNonOpaque)
 {
     sawNonOpaque = false;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
     RayShear sh = make_shear(r.d);
-    f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    f3 inv = traversal_rcp(r.d);
     int sp = 0; int32_t cur;
     if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
     else cur = 0;
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             float4 a, b, c, d; bvh.node(cur, a, b, c, d);
-            float lmin[3] = { a.x, a.y, a.z }, lmax[3] = { b.x, b.y, b.z };
-            float rmin[3] = { c.x, c.y, c.z }, rmax[3] = { d.x, d.y, d.z };
             int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
             float tl, tr;
-            bool hl = slab(lmin, lmax, r, inv, r.tmin, r.tmax, tl);
-            bool hr = slab(rmin, rmax, r, inv, r.tmin, r.tmax, tr);
-            if (hl && hr) { stack.push(sp++, ri); cur = li; continue; }
-            else if (hl) { cur = li; continue; }
-            else if (hr) { cur = ri; continue; }
-        } else {
+            bool hl = slab(a, b, r.o, inv, r.tmin, r.tmax, tl);
+            bool hr = slab(c, d, r.o, inv, r.tmin, r.tmax, tr);
+            if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
+            else if (hl) cur = li;
+            else if (hr) cur = ri;
+            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+        }
+        if (cur == kTraversalDone) break;
+        {
             uint32_t enc = (uint32_t)(~cur);
             uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
