@@ -115,6 +115,46 @@ inline void transform_point(const float* p, const float* M, float* o)
     o[2] = ((p[0] * M[2] + p[1] * M[6]) + p[2] * M[10]) + M[14];
 }
 
+inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline void cross3(const float* a, const float* b, float* o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline float half_to_float(uint32_t h)
+{
+    uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+    float f;
+    if (e == 0) {
+        if (m == 0) { u = s; memcpy(&f, &u, 4); return f; }
+        u = 0x33800000u; float scale; memcpy(&scale, &u, 4);
+        f = (float)m * scale;
+        return s ? -f : f;
+    }
+    u = (e == 31) ? (s | 0x7f800000u | (m << 13)) : (s | ((e + 112u) << 23) | (m << 13));
+    memcpy(&f, &u, 4);
+    return f;
+}
+// UnpackVertex, MeshCommon.hlsli:9-22 (normal, uv) and DecodeOct, Common.hlsli:174-181 (tangent)
+inline void unpack_normal(const HrptVertexQuantized& q, float* n)
+{
+    n[0] = (float)(q.m_Normal & 1023u) / 511.0f - 1.0f;
+    n[1] = (float)((q.m_Normal >> 10) & 1023u) / 511.0f - 1.0f;
+    n[2] = (float)((q.m_Normal >> 20) & 1023u) / 511.0f - 1.0f;
+}
+inline void unpack_uv(const HrptVertexQuantized& q, float* uv) { uv[0] = half_to_float(q.m_Uv & 0xFFFFu); uv[1] = half_to_float(q.m_Uv >> 16); }
+inline void unpack_tangent(const HrptVertexQuantized& q, float* t)
+{
+    float ex = (float)(q.m_Tangent & 255u) / 127.0f - 1.0f, ey = (float)((q.m_Tangent >> 8) & 255u) / 127.0f - 1.0f;
+    float v[3] = { ex, ey, (1.0f - std::fabs(ex)) - std::fabs(ey) };
+    float neg = -v[2];
+    float tt = (neg >= 0.0f) ? neg : 0.0f;      // max(-v.z, 0)
+    v[0] += (v[0] >= 0.0f) ? -tt : tt;
+    v[1] += (v[1] >= 0.0f) ? -tt : tt;
+    float inv = 1.0f / std::sqrt(dot3(v, v));   // normalize(v) = v * (1/sqrt(dot(v,v)))
+    t[0] = v[0] * inv; t[1] = v[1] * inv; t[2] = v[2] * inv;
+    t[3] = (q.m_Normal & (1u << 30)) != 0 ? -1.0f : 1.0f;
+}
+
 } // namespace
 
 bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
@@ -129,7 +169,7 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
         const HrptPerInstanceData& in = s.instances[i];
         if (in.m_MeshDataIndex >= s.meshDataCount) { error = "instance m_MeshDataIndex out of range"; return false; }
         if (in.m_MaterialIndex >= s.materialCount) { error = "instance m_MaterialIndex out of range"; return false; }
-        if (in.m_LODIndex >= 8) { error = "instance m_LODIndex out of range"; return false; }
+        if (in.m_LODIndex != 0) { error = "instance m_LODIndex must be 0 on the path-tracer path (TLASPatch does not run, PathTracer.hlsl:102)"; return false; }
         const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
         if ((uint64_t)md.m_IndexOffsets[0] + md.m_IndexCounts[0] > s.indexCount || md.m_IndexCounts[0] % 3 != 0) { error = "mesh LOD0 index range invalid"; return false; }
         triCount += md.m_IndexCounts[0] / 3;
@@ -151,6 +191,15 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
             tris.push_back(t);
         }
     }
+    // per-instance adjugate rows (TransformNormal, Common.hlsli:33-47)
+    out.instShade.resize(s.instanceCount);
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const float* M = s.instances[i].m_World;
+        const float r0[3] = { M[0], M[1], M[2] }, r1[3] = { M[4], M[5], M[6] }, r2[3] = { M[8], M[9], M[10] };
+        HostInstShade& is = out.instShade[i];
+        cross3(r1, r2, is.adj0); cross3(r2, r0, is.adj1); cross3(r0, r1, is.adj2);
+        is.adj0[3] = is.adj1[3] = is.adj2[3] = 0.0f;
+    }
     if (tris.empty()) return true;
 
     Builder b; b.src = &tris; b.out = &out;
@@ -170,6 +219,26 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     Box root;
     int32_t r = b.build(0, (uint32_t)tris.size(), 0, root);
     if (r < 0) { out.rootLeaf = r; out.nodes.clear(); }
+
+    // shading attributes in leaf order
+    bool needTangents = false;
+    for (uint32_t m = 0; m < s.materialCount; ++m) if (s.materials[m].m_TextureFlags & HRPT_TEXFLAG_NORMAL) needTangents = true;
+    out.attrs.resize(out.tris.size());
+    if (needTangents) out.tangents.resize(out.tris.size());
+    for (size_t k = 0; k < out.tris.size(); ++k) {
+        const HostTri& t = out.tris[k];
+        const HrptPerInstanceData& in = s.instances[t.inst];
+        const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
+        const uint32_t* ix = s.indices + md.m_IndexOffsets[0] + 3 * (size_t)t.prim;
+        HostTriAttr& a = out.attrs[k];
+        unpack_normal(s.vertices[ix[0]], a.n0); unpack_normal(s.vertices[ix[1]], a.n1); unpack_normal(s.vertices[ix[2]], a.n2);
+        unpack_uv(s.vertices[ix[0]], a.uv0); unpack_uv(s.vertices[ix[1]], a.uv1); unpack_uv(s.vertices[ix[2]], a.uv2);
+        a.material = in.m_MaterialIndex; a.inst = t.inst; a.prim = t.prim; a.pad[0] = a.pad[1] = 0;
+        if (needTangents) {
+            HostTriTangent& tg = out.tangents[k];
+            unpack_tangent(s.vertices[ix[0]], tg.t0); unpack_tangent(s.vertices[ix[1]], tg.t1); unpack_tangent(s.vertices[ix[2]], tg.t2);
+        }
+    }
     return true;
 }
 

@@ -29,11 +29,28 @@ struct HostTri {            // mirrors hrt::GpuTri, 48 B
     float p1[3]; uint32_t prim;
     float p2[3]; uint32_t flags;
 };
-static_assert(sizeof(HostNode) == 64 && sizeof(HostTri) == 48, "GPU layouts");
+// Shading attributes of one world triangle, unpacked ONCE at upload with exactly the arithmetic of UnpackVertex
+// (src/shaders/MeshCommon.hlsli:9-22): what GetTriangleVertices + UnpackVertex (RaytracingCommon.hlsli:33-50)
+// would produce per hit. 80 B, same (leaf) order as HostTri, so a hit is one index into both arrays.
+struct HostTriAttr {
+    float n0[3], n1[3], n2[3];      // decoded vertex normals (local space)
+    float uv0[2], uv1[2], uv2[2];   // f16tof32 texture coordinates
+    uint32_t material;              // PerInstanceData::m_MaterialIndex of the owning instance
+    uint32_t inst;                  // CommittedInstanceIndex
+    uint32_t prim;                  // CommittedPrimitiveIndex
+    uint32_t pad[2];
+};
+struct HostTriTangent { float t0[4], t1[4], t2[4]; };   // DecodeOct tangents + sign, only built when a normal map exists
+// MakeAdjugateMatrix(world) rows (Common.hlsli:33-41), computed once per instance with the same cross products.
+struct HostInstShade { float adj0[4], adj1[4], adj2[4]; };
+static_assert(sizeof(HostNode) == 64 && sizeof(HostTri) == 48 && sizeof(HostTriAttr) == 80 && sizeof(HostInstShade) == 48, "GPU layouts");
 
 struct BuiltBvh {
     std::vector<HostNode> nodes;    // empty when the scene fits one leaf
     std::vector<HostTri> tris;      // leaf order
+    std::vector<HostTriAttr> attrs; // parallel to tris
+    std::vector<HostTriTangent> tangents; // parallel to tris, empty unless some material samples a normal map
+    std::vector<HostInstShade> instShade; // per instance
     int32_t rootLeaf = 0;           // encoded leaf when nodes is empty and tris is not
     uint32_t maxDepth = 0;
 };

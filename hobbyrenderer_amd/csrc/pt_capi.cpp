@@ -162,11 +162,17 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
     v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
     v.rootLeaf = bvh.rootLeaf;
-    if ((r = upload(c, s->vertices, s->vertexCount, &v.vertices)) != HRPT_OK) return r;
-    if ((r = upload(c, s->indices, s->indexCount, &v.indices)) != HRPT_OK) return r;
-    v.indexCount = s->indexCount;
-    if ((r = upload(c, s->meshData, s->meshDataCount, &v.meshData)) != HRPT_OK) return r;
-    if ((r = upload(c, s->instances, s->instanceCount, &v.instances)) != HRPT_OK) return r;
+    // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
+    // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
+    const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
+    if ((r = upload(c, bvh.attrs.data(), bvh.attrs.size(), &da)) != HRPT_OK) return r;
+    if ((r = upload(c, bvh.instShade.data(), bvh.instShade.size(), &dis)) != HRPT_OK) return r;
+    v.attrs = reinterpret_cast<const GpuTriAttr*>(da); v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+    v.tangents = nullptr;
+    if (!bvh.tangents.empty()) {
+        if ((r = upload(c, bvh.tangents.data(), bvh.tangents.size(), &dtg)) != HRPT_OK) return r;
+        v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
+    }
     if ((r = upload(c, s->materials, s->materialCount, &v.materials)) != HRPT_OK) return r;
     if ((r = upload(c, s->lights, s->lightCount, &v.lights)) != HRPT_OK) return r;
     v.lightCount = s->lightCount;

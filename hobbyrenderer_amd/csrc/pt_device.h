@@ -68,16 +68,19 @@ struct GpuTri {             // 48 B world-space triangle (instance transform app
     float p1[3]; uint32_t prim;
     float p2[3]; uint32_t flags;    // bit 0: instance is ForceOpaque (src/Scene.cpp:150-154)
 };
+// Per-triangle shading attributes, unpacked once at upload (bvh_build.h HostTriAttr), and per-instance adjugate rows.
+struct GpuTriAttr { float4 a, b, c, d, e; };   // a{n0,n1.x} b{n1.yz,n2.xy} c{n2.z,uv0,uv1.x} d{uv1.y,uv2,material} e{inst,prim,-,-}
+struct GpuTriTangent { float4 t0, t1, t2; };
+struct GpuInstShade { float4 adj0, adj1, adj2; };
 struct GpuTexture { const uint8_t* rgba8; uint32_t w, h; };
 
 struct SceneView {
     const GpuNode* nodes; uint32_t nodeCount;
     const GpuTri* tris; uint32_t triCount;
     int32_t rootLeaf;       // when the whole scene fits one leaf: encoded leaf, else 0
-    const HrptVertexQuantized* vertices;
-    const uint32_t* indices; uint32_t indexCount;
-    const HrptMeshData* meshData;
-    const HrptPerInstanceData* instances;
+    const GpuTriAttr* attrs;            // parallel to tris
+    const GpuTriTangent* tangents;      // parallel to tris, or null when no material samples a normal map
+    const GpuInstShade* instShade;      // per instance
     const HrptMaterialConstants* materials;
     const HrptGPULight* lights; uint32_t lightCount;
     const GpuTexture* textures; uint32_t textureCount;
@@ -87,7 +90,7 @@ struct SceneView {
 
 // ------------------------------------------------------------------ rays and hits
 struct Ray { f3 o, d; float tmin, tmax; };
-struct Hit { float t; uint32_t inst, prim; float u, v; uint32_t opaque; bool valid; };
+struct Hit { float t; uint32_t inst, prim; float u, v; uint32_t opaque; uint32_t tri; bool valid; };
 struct HitKey { float t; uint32_t inst, prim; bool have; };
 
 struct RayShear { int kx, ky, kz; float Sx, Sy, Sz; };
@@ -180,7 +183,7 @@ HRT_DEV f3 traversal_rcp(f3 d)
 template <class BVH, class STACK>
 HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack)
 {
-    Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0;
+    Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0; best.tri = 0;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
     RayShear sh = make_shear(r.d);
     f3 inv = traversal_rcp(r.d);
@@ -216,7 +219,7 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
                     bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
                     if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
                         best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
-                        best.opaque = __float_as_uint(c.w) & 1u;
+                        best.opaque = __float_as_uint(c.w) & 1u; best.tri = first + i;
                         tlim = t;
                     }
                 }
@@ -270,60 +273,33 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     return false;
 }
 
-// ------------------------------------------------------------------ vertex fetch
-struct Vtx { f3 pos, normal; f2 uv; f4 tangent; };
-
-// DecodeOct, Common.hlsli:174-181
-HRT_DEV f3 decode_oct(float ex, float ey)
+// ------------------------------------------------------------------ triangle attributes
+// What GetTriangleVertices + UnpackVertex (RaytracingCommon.hlsli:33-50, MeshCommon.hlsli:9-22) yield for a hit,
+// read from the per-triangle record built at upload (the quantised vertex / index buffers are consumed there).
+struct TriVerts { f3 n0, n1, n2; f2 uv0, uv1, uv2; uint32_t material, inst; };
+HRT_DEV TriVerts load_tri_attr(const SceneView& s, uint32_t tri)
 {
-    f3 v = mk3(ex, ey, (1.0f - hrt_abs(ex)) - hrt_abs(ey));
-    float t = hrt_max(-v.z, 0.0f);
-    v.x += (v.x >= 0.0f) ? -t : t;
-    v.y += (v.y >= 0.0f) ? -t : t;
-    return normalize(v);
-}
-// UnpackVertex, MeshCommon.hlsli:9-22
-HRT_DEV Vtx unpack_vertex(const HrptVertexQuantized& q, bool wantTangent)
-{
-    Vtx v;
-    v.pos = mk3(q.m_Pos);
-    v.normal.x = (float)(q.m_Normal & 1023u) / 511.0f - 1.0f;
-    v.normal.y = (float)((q.m_Normal >> 10) & 1023u) / 511.0f - 1.0f;
-    v.normal.z = (float)((q.m_Normal >> 20) & 1023u) / 511.0f - 1.0f;
-    if (wantTangent) {
-        float ox = (float)(q.m_Tangent & 255u) / 127.0f - 1.0f;
-        float oy = (float)((q.m_Tangent >> 8) & 255u) / 127.0f - 1.0f;
-        f3 tg = decode_oct(ox, oy);
-        v.tangent.x = tg.x; v.tangent.y = tg.y; v.tangent.z = tg.z;
-    } else { v.tangent.x = 0; v.tangent.y = 0; v.tangent.z = 0; }
-    v.tangent.w = (q.m_Normal & (1u << 30)) != 0 ? -1.0f : 1.0f;
-    v.uv.x = hrt_f16tof32(q.m_Uv & 0xFFFFu); v.uv.y = hrt_f16tof32(q.m_Uv >> 16);
-    return v;
-}
-// GetTriangleVertices, RaytracingCommon.hlsli:33-50 (out-of-range structured reads return 0 like D3D)
-HRT_DEV void get_triangle_vertices(const SceneView& s, uint32_t prim, uint32_t indexBase, Vtx tv[3], bool wantTangent)
-{
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        uint32_t ii = indexBase + 3u * prim + (uint32_t)k;
-        uint32_t vi = (ii < s.indexCount) ? s.indices[ii] : 0u;
-        HrptVertexQuantized q = s.vertices[vi];
-        tv[k] = unpack_vertex(q, wantTangent);
-    }
+    const float4* p = reinterpret_cast<const float4*>(s.attrs + tri);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriVerts t;
+    t.n0 = mk3(a.x, a.y, a.z); t.n1 = mk3(a.w, b.x, b.y); t.n2 = mk3(b.z, b.w, c.x);
+    t.uv0.x = c.y; t.uv0.y = c.z; t.uv1.x = c.w; t.uv1.y = d.x; t.uv2.x = d.y; t.uv2.y = d.z;
+    t.material = __float_as_uint(d.w); t.inst = __float_as_uint(e.x);
+    return t;
 }
 // GetInterpolatedUV, RaytracingCommon.hlsli:79-89
-HRT_DEV f2 interpolated_uv(const Vtx tv[3], float bx, float by)
+HRT_DEV f2 interpolated_uv(const TriVerts& tv, float bx, float by)
 {
     float w0 = (1.0f - bx) - by; f2 r;
-    r.x = (tv[0].uv.x * w0 + tv[1].uv.x * bx) + tv[2].uv.x * by;
-    r.y = (tv[0].uv.y * w0 + tv[1].uv.y * bx) + tv[2].uv.y * by;
+    r.x = (tv.uv0.x * w0 + tv.uv1.x * bx) + tv.uv2.x * by;
+    r.y = (tv.uv0.y * w0 + tv.uv1.y * bx) + tv.uv2.y * by;
     return r;
 }
 // TransformNormal, Common.hlsli:33-47
-HRT_DEV f3 transform_normal(f3 n, const float* M)
+HRT_DEV f3 transform_normal(f3 n, const GpuInstShade& is)
 {
-    f3 r0 = mk3(M[0], M[1], M[2]), r1 = mk3(M[4], M[5], M[6]), r2 = mk3(M[8], M[9], M[10]);
-    f3 a0 = cross(r1, r2), a1 = cross(r2, r0), a2 = cross(r0, r1);
+    // adjugate rows cross(r1,r2), cross(r2,r0), cross(r0,r1) are precomputed per instance with the same arithmetic
+    f3 a0 = mk3(is.adj0.x, is.adj0.y, is.adj0.z), a1 = mk3(is.adj1.x, is.adj1.y, is.adj1.z), a2 = mk3(is.adj2.x, is.adj2.y, is.adj2.z);
     f3 o = mk3((n.x * a0.x + n.y * a1.x) + n.z * a2.x,
                (n.x * a0.y + n.y * a1.y) + n.z * a2.y,
                (n.x * a0.z + n.y * a1.z) + n.z * a2.z);
@@ -676,24 +652,23 @@ struct SurfaceAttr { f3 worldPos, worldNormal, worldTangent; float tangentSign; 
 struct Pbr { f3 baseColor; float alpha, roughness, metallic; f3 emissive, normal; };
 
 // GetFullHitAttributes, RaytracingCommon.hlsli:52-77 (LOD 0: PathTracer.hlsl:103)
-HRT_DEV SurfaceAttr full_hit_attributes(const SceneView& s, const Hit& hit, const Ray& ray, const HrptPerInstanceData& inst,
-                                        uint32_t indexBase, bool wantTangent)
+HRT_DEV SurfaceAttr full_hit_attributes(const SceneView& s, const Hit& hit, const Ray& ray, const TriVerts& tv, const GpuInstShade& is, bool wantTangent)
 {
-    Vtx tv[3]; get_triangle_vertices(s, hit.prim, indexBase, tv, wantTangent);
     float bx = (1.0f - hit.u) - hit.v, by = hit.u, bz = hit.v;
     SurfaceAttr a;
     a.worldPos = ray.o + ray.d * hit.t;
-    f3 ln = (tv[0].normal * bx + tv[1].normal * by) + tv[2].normal * bz;
-    a.worldNormal = transform_normal(ln, inst.m_World);
-    if (wantTangent) {
-        f3 t0 = mk3(tv[0].tangent.x, tv[0].tangent.y, tv[0].tangent.z), t1 = mk3(tv[1].tangent.x, tv[1].tangent.y, tv[1].tangent.z),
-           t2 = mk3(tv[2].tangent.x, tv[2].tangent.y, tv[2].tangent.z);
+    f3 ln = (tv.n0 * bx + tv.n1 * by) + tv.n2 * bz;
+    a.worldNormal = transform_normal(ln, is);
+    a.tangentSign = 1.0f;
+    if (wantTangent && s.tangents) {
+        GpuTriTangent tg = s.tangents[hit.tri];
+        f3 t0 = mk3(tg.t0.x, tg.t0.y, tg.t0.z), t1 = mk3(tg.t1.x, tg.t1.y, tg.t1.z), t2 = mk3(tg.t2.x, tg.t2.y, tg.t2.z);
         f3 lt = (t0 * bx + t1 * by) + t2 * bz;
-        a.worldTangent = transform_normal(lt, inst.m_World);
+        a.worldTangent = transform_normal(lt, is);
+        a.tangentSign = (tg.t0.w * bx + tg.t1.w * by) + tg.t2.w * bz;
     } else a.worldTangent = mk3(0.0f, 0.0f, 0.0f);
-    a.tangentSign = (tv[0].tangent.w * bx + tv[1].tangent.w * by) + tv[2].tangent.w * bz;
-    a.uv.x = (tv[0].uv.x * bx + tv[1].uv.x * by) + tv[2].uv.x * bz;
-    a.uv.y = (tv[0].uv.y * bx + tv[1].uv.y * by) + tv[2].uv.y * bz;
+    a.uv.x = (tv.uv0.x * bx + tv.uv1.x * by) + tv.uv2.x * bz;
+    a.uv.y = (tv.uv0.y * bx + tv.uv1.y * by) + tv.uv2.y * bz;
     return a;
 }
 // TransformNormalWithTBN, Common.hlsli:183-200

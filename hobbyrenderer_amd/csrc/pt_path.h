@@ -56,12 +56,11 @@ HRT_DEV bool trace_standard(const SceneView& s, const BVH& bvh, const Ray& ray, 
         Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
         if (!h.valid) return false;
         if (h.opaque) { out = h; return true; }
-        const HrptPerInstanceData& inst = s.instances[h.inst];
-        const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
+        TriVerts tv = load_tri_attr(s, h.tri);
+        const HrptMaterialConstants& mat = s.materials[tv.material];
         uint32_t alphaMode = mat.m_AlphaMode;
         bool commit = false;
         if (alphaMode == HRPT_ALPHA_MODE_MASK || (alphaMode == HRPT_ALPHA_MODE_BLEND && !(mat.m_TransmissionFactor > 0.0f))) {
-            Vtx tv[3]; get_triangle_vertices(s, h.prim, s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[0], tv, false);
             f2 uv = interpolated_uv(tv, h.u, h.v);
             float alpha = candidate_alpha(s, mat, uv);
             if (alphaMode == HRPT_ALPHA_MODE_MASK) commit = alpha >= mat.m_AlphaCutoff;      // AlphaTest :91-110
@@ -88,10 +87,8 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
     for (;;) {
         Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
         if (!h.valid) break;
-        const HrptPerInstanceData& inst = s.instances[h.inst];
-        const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
-        uint32_t indexBase = s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[inst.m_LODIndex];   // inst.m_LODIndex, :423
-        Vtx tv[3]; get_triangle_vertices(s, h.prim, indexBase, tv, false);
+        TriVerts tv = load_tri_attr(s, h.tri);     // inst.m_LODIndex is 0 on this path (validated at upload), :423
+        const HrptMaterialConstants& mat = s.materials[tv.material];
         f2 uv = interpolated_uv(tv, h.u, h.v);
         if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
             // AlphaTestGrad on single-mip textures == level-0 sample at the interpolated uv (RaytracingCommon.hlsli:112-130,207-240)
@@ -102,8 +99,8 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
             transmission *= (1.0f - opacity);
             if (mat.m_TransmissionFactor > 0.0f && mat.m_IsThinSurface == 0) {
                 float w0 = (1.0f - h.u) - h.v;
-                f3 ln = (tv[0].normal * w0 + tv[1].normal * h.u) + tv[2].normal * h.v;
-                f3 wn = normalize(transform_normal(ln, inst.m_World));
+                f3 ln = (tv.n0 * w0 + tv.n1 * h.u) + tv.n2 * h.v;
+                f3 wn = normalize(transform_normal(ln, s.instShade[tv.inst]));
                 bool front = dot(wn, ray.d) < 0.0f;
                 if (front) { inVolume = true; inVolumeStartT = h.t; sigmaT = mk3(mat.m_SigmaA) + mk3(mat.m_SigmaS); }
                 else if (inVolume) {
@@ -128,13 +125,15 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
 // One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908): early-outs, the jittered sample
 // (2 RNG draws when reached), per-sample byproducts and the unshadowed EvaluateDirectLight terms.
 // Returns false when the light contributes nothing and casts no shadow ray.
-HRT_DEV bool nee_sample(const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunRadiance, f3 sunDirection, float cosSun,
+HRT_DEV bool nee_sample(const SceneView& s, const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunDirection, float sunIntensity, float cosSun,
                         uint32_t& rng, f3& L, float& maxDist, f3& diffuse, f3& specular)
 {
     f3 radiance;
     if (l.m_Type == HRPT_LIGHT_DIRECTIONAL) {                                   // :716-745
         if (dot(in.N, sunDirection) <= 0.0f) return false;
-        radiance = sunRadiance;
+        // inputs.sunRadiance (PathTracer.hlsl:137) is a pure function of the hit position and is only read past this
+        // early-out, so it is evaluated here (one transmittance-LUT fetch) instead of for every hit.
+        radiance = atm::sun_radiance(s, atm::atmosphere_pos(worldPos), sunDirection, sunIntensity);
         float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
         L = sample_cone(sunDirection, cosSun, ux, uy);
         maxDist = 1e10f;
@@ -186,9 +185,9 @@ template <class EMIT>
 HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, const Hit& hit,
                                        SurfaceCarry& carry, EMIT&& emit)
 {
-    const HrptPerInstanceData& inst = s.instances[hit.inst];
-    const HrptMaterialConstants& mat = s.materials[inst.m_MaterialIndex];
-    uint32_t indexBase = s.meshData[inst.m_MeshDataIndex].m_IndexOffsets[0];      // LOD 0, :103
+    TriVerts tv = load_tri_attr(s, hit.tri);                                      // inst/mesh/vertex fetch :92-94,:104 (LOD 0, :103)
+    GpuInstShade is = s.instShade[tv.inst];
+    const HrptMaterialConstants& mat = s.materials[tv.material];
     uint32_t texFlags = mat.m_TextureFlags;
 
     if (ps.inVolume) {                                                            // Beer-Lambert :97-100
@@ -196,10 +195,9 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
                     hrt_exp(-(ps.sigmaA.z + ps.sigmaS.z) * hit.t));
         ps.throughput = ps.throughput * tr;
     }
-    SurfaceAttr attr = full_hit_attributes(s, hit, ps.ray, inst, indexBase, (texFlags & HRPT_TEXFLAG_NORMAL) != 0);
+    SurfaceAttr attr = full_hit_attributes(s, hit, ps.ray, tv, is, (texFlags & HRPT_TEXFLAG_NORMAL) != 0);
     Pbr pbr = pbr_attributes(s, attr, mat);
 
-    f3 p_atmo = atm::atmosphere_pos(attr.worldPos);
     f3 Ng = normalize(attr.worldNormal);
     f3 N = pbr.normal;
     f3 V = -ps.ray.d;
@@ -212,7 +210,6 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     Lighting in;
     in.N = N; in.V = V; in.L = mk3(0.0f, 0.0f, 0.0f); in.baseColor = pbr.baseColor;
     in.roughness = pbr.roughness; in.metallic = pbr.metallic; in.ior = mat.m_IOR;
-    f3 sunRadiance = atm::sun_radiance(s, p_atmo, sunDir, sunIntensity);
     prepare_byproducts(in);                                                       // :142 (L = 0 => H = V)
 
     if (mat.m_TransmissionFactor > 0.0f || mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {    // :149-255
@@ -264,7 +261,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
         HrptGPULight l;
         if (i < s.lightCount) l = s.lights[i]; else { l = HrptGPULight(); l.m_Type = 0; }   // OOB structured read = zeros
         f3 L, dif, spec; float maxDist;
-        if (nee_sample(l, in, attr.worldPos, sunRadiance, sunDir, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
+        if (nee_sample(s, l, in, attr.worldPos, sunDir, sunIntensity, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
             emit(i, attr.worldPos, L, maxDist, dif, spec);
     }
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;

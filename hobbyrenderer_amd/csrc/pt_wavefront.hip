@@ -7,7 +7,7 @@
 //
 // Data layout in HBM (one pool, SoA of float4, all streams coalesced 16 B/lane):
 //   path queues A/B (ping-pong per bounce): rayO{o.xyz,tmin} rayD{d.xyz,rng} thr{T.xyz,sample} [med0{sigmaA,ior} med1{sigmaS,inVolume}]
-//   hit records of the current queue:       hitA{t,u,v,prim} hitI{inst}
+//   hit records of the current queue:       hit{t,u,v,triangle}  (triangle = leaf-order index, 0xFFFFFFFF = miss)
 //   shadow queue:                           sh0{origin,sample} sh1{T,count} + per light sample shL{L,maxDist} shD{diffuse} shS{specular}
 //   sampleRadiance[sample] (rgb): one slot per (pixel, accumulation index); emissive / NEE / sky are added in path order,
 //                                 wf_resolve then folds the indices in order exactly like progressive accumulation (:332-339).
@@ -37,7 +37,7 @@ constexpr size_t kLdsBudget = 64 * 1024;     // dynamic LDS per block: traversal
 struct WfBuffers {
     float4 *rayO[2], *rayD[2], *thr[2], *med0[2], *med1[2];
     uint32_t* pathCnt[2];
-    float4* hitA; uint32_t* hitI;
+    float4* hit;
     float4 *sh0, *sh1, *shL, *shD, *shS;
     uint32_t* shadowCnt;
     float4* radiance;
@@ -186,8 +186,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                 if (LDS_BVH) hit = trace_standard(a.scene, lbvh, r, rng, stack, h);
                 else hit = trace_standard(a.scene, gbvh, r, rng, stack, h);
                 if (a.hasStochasticAlpha && rng != rng0) { d.w = __uint_as_float(rng); rayD[slot] = d; }
-                a.b.hitA[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-                a.b.hitI[slot] = hit ? h.inst : 0xFFFFFFFFu;
+                a.b.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(hit ? h.tri : 0xFFFFFFFFu));
                 ++nRays;
             }
         }
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
             if (valid) {
                 uint32_t slot = segBase + i;
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
-                float4 ha = a.b.hitA[slot]; uint32_t inst = a.b.hitI[slot];
+                float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
                 ps.ray.o = mk3(o.x, o.y, o.z); ps.ray.d = mk3(d.x, d.y, d.z); ps.ray.tmin = o.w; ps.ray.tmax = 1e10f;
                 ps.rng = __float_as_uint(d.w);
                 ps.throughput = mk3(t.x, t.y, t.z); smp = __float_as_uint(t.w);
@@ -229,8 +228,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                     ps.sigmaA = mk3(m0.x, m0.y, m0.z); ps.interiorIOR = m0.w; ps.sigmaS = mk3(m1.x, m1.y, m1.z); ps.inVolume = m1.w != 0.0f;
                 } else { ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); ps.interiorIOR = 1.0f; ps.inVolume = false; }
                 bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
-                if (inst != 0xFFFFFFFFu) {
-                    Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.prim = __float_as_uint(ha.w); h.inst = inst; h.opaque = 1;
+                if (tri != 0xFFFFFFFFu) {
+                    Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
                     SurfaceCarry carry;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
                     SurfaceOutcome oc = shade_surface_a(s, cb, ps, h, carry, [&](uint32_t, f3 wp, f3 L, float maxDist, f3 dif, f3 spec) {
@@ -442,7 +441,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         if (traits.hasMedium) { oMed0[p] = carve(capacity * 16); oMed1[p] = carve(capacity * 16); }
         oCnt[p] = carve((size_t)segs * 4);
     }
-    size_t oHitA = carve(capacity * 16), oHitI = carve(capacity * 4);
+    size_t oHit = carve(capacity * 16);
     size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16);
     size_t oShL = carve(capacity * 16 * maxLights), oShD = carve(capacity * 16 * maxLights), oShS = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
@@ -459,7 +458,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         a.b.rayO[p] = (float4*)(base + oRayO[p]); a.b.rayD[p] = (float4*)(base + oRayD[p]); a.b.thr[p] = (float4*)(base + oThr[p]);
         a.b.med0[p] = (float4*)(base + oMed0[p]); a.b.med1[p] = (float4*)(base + oMed1[p]); a.b.pathCnt[p] = (uint32_t*)(base + oCnt[p]);
     }
-    a.b.hitA = (float4*)(base + oHitA); a.b.hitI = (uint32_t*)(base + oHitI);
+    a.b.hit = (float4*)(base + oHit);
     a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1);
     a.b.shL = (float4*)(base + oShL); a.b.shD = (float4*)(base + oShD); a.b.shS = (float4*)(base + oShS);
     a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
