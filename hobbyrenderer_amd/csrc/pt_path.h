@@ -46,6 +46,23 @@ HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_
     ps.inVolume = false; ps.interiorIOR = 1.0f; ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f);
 }
 
+// The candidate branch of TraceRayStandard (RaytracingCommon.hlsli:153-184) for a hit on a ForceNonOpaque instance:
+// MASK -> AlphaTest (:91-110); BLEND -> transmissive materials always commit, others commit with probability alpha
+// (one RNG draw, :181).
+HRT_DEV bool candidate_commits(const SceneView& s, const Hit& h, uint32_t& rng)
+{
+    TriVerts tv = load_tri_attr(s, h.tri);
+    const HrptMaterialConstants& mat = s.materials[tv.material];
+    uint32_t alphaMode = mat.m_AlphaMode;
+    if (alphaMode == HRPT_ALPHA_MODE_MASK || (alphaMode == HRPT_ALPHA_MODE_BLEND && !(mat.m_TransmissionFactor > 0.0f))) {
+        f2 uv = interpolated_uv(tv, h.u, h.v);
+        float alpha = candidate_alpha(s, mat, uv);
+        if (alphaMode == HRPT_ALPHA_MODE_MASK) return alpha >= mat.m_AlphaCutoff;
+        return hrt_rng_next(&rng) < hrt_saturate(alpha);
+    }
+    return alphaMode == HRPT_ALPHA_MODE_BLEND;
+}
+
 // TraceRayStandard, RaytracingCommon.hlsli:138-198. Non-opaque candidates are visited front to back:
 // a rejected candidate becomes the exclusive lower bound of the next closest-hit query.
 template <class BVH, class STACK>
@@ -55,18 +72,7 @@ HRT_DEV bool trace_standard(const SceneView& s, const BVH& bvh, const Ray& ray, 
     for (;;) {
         Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
         if (!h.valid) return false;
-        if (h.opaque) { out = h; return true; }
-        TriVerts tv = load_tri_attr(s, h.tri);
-        const HrptMaterialConstants& mat = s.materials[tv.material];
-        uint32_t alphaMode = mat.m_AlphaMode;
-        bool commit = false;
-        if (alphaMode == HRPT_ALPHA_MODE_MASK || (alphaMode == HRPT_ALPHA_MODE_BLEND && !(mat.m_TransmissionFactor > 0.0f))) {
-            f2 uv = interpolated_uv(tv, h.u, h.v);
-            float alpha = candidate_alpha(s, mat, uv);
-            if (alphaMode == HRPT_ALPHA_MODE_MASK) commit = alpha >= mat.m_AlphaCutoff;      // AlphaTest :91-110
-            else commit = hrt_rng_next(&rng) < hrt_saturate(alpha);                          // stochastic coverage :181
-        } else if (alphaMode == HRPT_ALPHA_MODE_BLEND) commit = true;                        // transmissive: BSDF decides :181
-        if (commit) { out = h; return true; }
+        if (h.opaque || candidate_commits(s, h, rng)) { out = h; return true; }
         lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
     }
 }

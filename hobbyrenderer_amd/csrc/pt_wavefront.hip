@@ -160,6 +160,11 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 }
 
 // ------------------------------------------------------------------ extend (closest hit)
+// Persistent while-while traversal with lane refill: a wave keeps up to 64 rays of its segment in flight; whenever
+// at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
+// so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
+constexpr uint32_t kRefillMin = 12;
+
 template <bool LDS_BVH, int DEPTH>
 __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 {
@@ -167,27 +172,96 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
     LdsStack<DEPTH> stack; LdsBvh lbvh;
     setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
     GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+    const SceneView& s = a.scene;
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     const float4* __restrict__ rayO = a.b.rayO[parity];
     float4* __restrict__ rayD = a.b.rayD[parity];
     unsigned int nRays = 0;
+    const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
+
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
         const uint32_t cnt = a.b.pathCnt[parity][seg], segBase = seg * kSegment;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            uint32_t i = base + lane;
-            if (i < cnt) {
-                uint32_t slot = segBase + i;
-                float4 o = rayO[slot], d = rayD[slot];
-                Ray r; r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = 1e10f;
-                uint32_t rng = __float_as_uint(d.w), rng0 = rng;
-                Hit h; bool hit;
-                if (LDS_BVH) hit = trace_standard(a.scene, lbvh, r, rng, stack, h);
-                else hit = trace_standard(a.scene, gbvh, r, rng, stack, h);
-                if (a.hasStochasticAlpha && rng != rng0) { d.w = __uint_as_float(rng); rayD[slot] = d; }
-                a.b.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(hit ? h.tri : 0xFFFFFFFFu));
-                ++nRays;
+        uint32_t next = 0;                       // wave-uniform: next ray of the segment to hand out
+        // per-lane traversal state
+        bool active = false;
+        Ray r; r.o = mk3(0.0f, 0.0f, 0.0f); r.d = mk3(0.0f, 0.0f, 1.0f); r.tmin = 0.0f; r.tmax = 1e10f;
+        RayShear sh = make_shear(r.d); f3 inv = mk3(0.0f, 0.0f, 0.0f);
+        HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
+        Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
+        int32_t cur = kTraversalDone; int sp = 0; uint32_t slot = 0, rng = 0, rng0 = 0; float tlim = 0.0f;
+        for (;;) {
+            // ---- refill idle lanes
+            unsigned long long mIdle = __ballot(!active);
+            uint32_t nIdle = (uint32_t)__popcll(mIdle);
+            if (next < cnt && (nIdle >= kRefillMin || nIdle == 64u)) {
+                uint32_t idx = next + prefix_rank(mIdle);
+                if (!active && idx < cnt) {
+                    slot = segBase + idx;
+                    float4 o = rayO[slot], d = rayD[slot];
+                    r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = 1e10f;
+                    rng = __float_as_uint(d.w); rng0 = rng;
+                    lower.have = false;
+                    best.valid = false; tlim = r.tmax; sp = 0;
+                    bool finite = (r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z);
+                    sh = make_shear(r.d); inv = traversal_rcp(r.d);
+                    cur = (emptyScene || !finite) ? kTraversalDone : (s.nodeCount == 0 ? s.rootLeaf : 0);
+                    active = true; ++nRays;
+                }
+                next += nIdle;
+            }
+            if (__ballot(active) == 0ull) break;
+            if (active) {
+                // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
+                while (cur >= 0) {
+                    float4 na, nb, nc, nd;
+                    if (LDS_BVH) lbvh.node(cur, na, nb, nc, nd); else gbvh.node(cur, na, nb, nc, nd);
+                    int32_t li = __float_as_int(na.w), ri = __float_as_int(nb.w);
+                    float tl, tr;
+                    bool hl = slab(na, nb, r.o, inv, r.tmin, tlim, tl);
+                    bool hr = slab(nc, nd, r.o, inv, r.tmin, tlim, tr);
+                    if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
+                    else if (hl) cur = li;
+                    else if (hr) cur = ri;
+                    else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+                }
+                // ---- intersect the leaf
+                if (cur != kTraversalDone) {
+                    uint32_t enc = (uint32_t)(~cur);
+                    uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
+                    for (uint32_t i = 0; i < count; ++i) {
+                        float4 ta, tb, tc;
+                        if (LDS_BVH) lbvh.tri(first + i, ta, tb, tc); else gbvh.tri(first + i, ta, tb, tc);
+                        float t, u, v;
+                        if (tri_test(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), r, sh, t, u, v)) {
+                            uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
+                            bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+                            if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
+                                best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
+                                best.opaque = __float_as_uint(tc.w) & 1u; best.tri = first + i;
+                                tlim = t;
+                            }
+                        }
+                    }
+                    cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+                }
+                // ---- traversal finished: candidate resolution (TraceRayStandard) and hit record
+                if (cur == kTraversalDone) {
+                    bool done = true;
+                    if (best.valid && !best.opaque && !candidate_commits(s, best, rng)) {
+                        // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
+                        lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
+                        best.valid = false; tlim = r.tmax; sp = 0;
+                        cur = s.nodeCount == 0 ? s.rootLeaf : 0;
+                        done = false;
+                    }
+                    if (done) {
+                        if (a.hasStochasticAlpha && rng != rng0) { float4 d = rayD[slot]; d.w = __uint_as_float(rng); rayD[slot] = d; }
+                        a.b.hit[slot] = make_float4(best.t, best.u, best.v, __uint_as_float(best.valid ? best.tri : 0xFFFFFFFFu));
+                        active = false;
+                    }
+                }
             }
         }
     }
