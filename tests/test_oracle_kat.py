@@ -116,36 +116,7 @@ def test_detmath_accuracy():
 
 
 # ---- BVH-independence of the hit definition -----------------------------------------------------------
-def _random_soup(luts, n_tris, seed, blend_fraction=0.0, mask_fraction=0.0):
-    rng = np.random.default_rng(seed)
-    b = scenes.SceneBuilder()
-    n_mesh = 6
-    per = max(1, n_tris // n_mesh)
-    mats = [b.add_material(m_BaseColor=tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,))]
-    if blend_fraction:
-        mats.append(b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_BaseColor=(0.8, 0.6, 0.4, 0.5)))
-        mats.append(b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_TransmissionFactor=1.0, m_IOR=1.5, m_SigmaA=(0.5, 0.2, 0.1),
-                                   m_RoughnessMetallic=(0.05, 0.0)))
-        mats.append(b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_TransmissionFactor=0.7, m_IsThinSurface=1, m_RoughnessMetallic=(0.4, 0.0)))
-    if mask_fraction:
-        mats.append(b.add_material(m_AlphaMode=S.ALPHA_MODE_MASK, m_BaseColor=(0.5, 0.9, 0.5, 0.3), m_AlphaCutoff=0.5))
-        mats.append(b.add_material(m_AlphaMode=S.ALPHA_MODE_MASK, m_BaseColor=(0.5, 0.9, 0.5, 0.9), m_AlphaCutoff=0.5))
-    for m in range(n_mesh):
-        verts, idx = [], []
-        for t in range(per):
-            c = rng.uniform(-1.5, 1.5, 3)
-            p = c + rng.uniform(-0.5, 0.5, (3, 3))
-            nrm = np.cross(p[1] - p[0], p[2] - p[0]); nrm /= np.linalg.norm(nrm) + 1e-12
-            for k in range(3):
-                verts.append(scenes.quantize_vertex(p[k], nrm, rng.uniform(0, 1, 2), (1, 0, 0), 1.0))
-            idx += [3 * t, 3 * t + 1, 3 * t + 2]
-        mesh = b.add_mesh(np.array(verts, S.VertexQuantized), np.array(idx, np.uint32))
-        mat = mats[m % len(mats)]
-        ang = rng.uniform(0, 2 * math.pi)
-        rot = [[math.cos(ang), 0, -math.sin(ang)], [0, 1, 0], [math.sin(ang), 0, math.cos(ang)]]
-        b.add_instance(mesh, mat, scenes._mat(tuple(rng.uniform(0.5, 1.5, 3)), rot, tuple(rng.uniform(-0.5, 0.5, 3))))
-    b.add_light(S.LIGHT_POINT, position=(0.3, 2.5, -0.4), color=(1, 0.9, 0.8), intensity=20.0, radius=0.1)
-    return b.finalize(luts)
+from scene_helpers import random_soup as _random_soup
 
 
 @pytest.mark.parametrize("seed,blend,mask", [(3, 0.0, 0.0), (4, 0.5, 0.0), (5, 0.5, 0.3)])
