@@ -29,11 +29,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-class _DevMem:
-    """Exposes a library-owned device buffer to torch through __cuda_array_interface__ (zero copy)."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under
+    profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -77,21 +84,22 @@ def main():
     cb = scenes.fill_constants(view, pos, sc, 0, bounces)
     flags = {"default": S.FRAME_DEFAULT, "megakernel": S.FRAME_MEGAKERNEL, "wavefront": S.FRAME_WAVEFRONT}[args.mode]
 
-    # row-band sharding; bands are contiguous in the row-major accumulation image
-    if H % world != 0:
-        raise SystemExit(f"height {H} must be divisible by the number of GPUs {world} (equal contiguous all-gather shards)")
-    rows = H // world
-    y0, y1 = rank * rows, (rank + 1) * rows
-    tile = (0, y0, W, y1) if world > 1 else (0, 0, 0, 0)
+    # row-band sharding (hobbyrenderer_amd/distributed.py); bands are contiguous in the row-major accumulation image
+    from hobbyrenderer_amd.distributed import band_for_rank, device_tensor, render_sharded
+    y0, y1 = band_for_rank(H, world, rank)
+    rows = y1 - y0
     accum_ptr, _ = ctx.device_images()
-    full = torch.as_tensor(_DevMem(accum_ptr, (H, W, 4)), device=dev) if world > 1 else None
+    full = device_tensor(accum_ptr, (H, W, 4), dev) if world > 1 else None
+
+    def render_band(b0, b1):
+        ctx.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags)
+        ctx.synchronize()                                       # library stream -> host; RCCL runs on torch's stream
 
     def step():
-        ctx.render(cb, accum_count=spp, tile=tile, flags=flags)
-        if world > 1:
-            ctx.synchronize()                                   # library stream -> host; RCCL runs on torch's stream
-            band = full[y0:y1].clone()                          # 33.18 MB / N per rank
-            dist.all_gather_into_tensor(full, band)             # the single collective of the path
+        if world == 1:
+            ctx.render(cb, accum_count=spp, flags=flags)
+        else:
+            render_sharded(render_band, full, rank, world, dist.all_gather_into_tensor)   # the single collective
             torch.cuda.synchronize(dev)
             ctx.resolve_output()                                # Output = accum.rgb / accum.a on every rank
 
@@ -142,8 +150,8 @@ def main():
             from oracle.binding import Oracle, OrStats
             o = Oracle(sc)
             ost = OrStats()
-            cores = os.cpu_count() or 1
-            sample_spp = 1
+            cores = min(16, len(os.sched_getaffinity(0)))   # the CPU share of a one-GPU box
+            sample_spp = spp                                 # the whole workload: ~10 s of CPU work on 16 cores
             t1 = time.perf_counter()
             o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), W, H, sample_spp, nthreads=cores, stats=ost)
             cpu_s = time.perf_counter() - t1
@@ -154,7 +162,7 @@ def main():
             result["cpu_baseline"] = {
                 "value": (d["closestRays"] + d["shadowRays"]) / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                 "sample": f"oracle (CPU restatement of the reference shader; the reference has no CPU path), same scene, {W}x{H}, "
-                          f"accumulation index 0 only ({sample_spp} of {spp} spp), {bounces} bounces, {cores} pthreads, {cpu_s:.2f} s"}
+                          f"accumulation indices 0..{sample_spp - 1} ({sample_spp} of {spp} spp), {bounces} bounces, {cores} pthreads, {cpu_s:.2f} s"}
         if n_c is None:
             # constants measured by the oracle on config 2 (Measurement); used when the oracle leg is skipped
             n_c, t_c, n_s, t_s = 16.14, 2.60, 17.37, 2.71
@@ -164,20 +172,33 @@ def main():
         px0 = (y1 - y0) * W if world > 1 else W * H
         step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
         if st.traceKernelLaunches > 0:
-            # wavefront: the dominant kernel is the persistent closest-hit trace kernel (one launch per bounce)
-            launches = st.traceKernelLaunches
-            per_launch_bytes = r0_closest * (32.0 + 20.0 + 32.0 * n_c + 48.0 * t_c) / launches   # ray record + hit record + traversal
-            avg_ms = st.traceKernelMs / launches
-            kernel = "pt_wf_extend"
+            # wavefront: per-class device time from HIP events the library records on ITS stream around every launch.
+            # SURVEY 8(d) bytes split by the kernel that touches them (the three classes sum to B_closest / B_shadow):
+            #   wf_extend: ray record 32 + traversal 32n+48t + hit record 20 per closest ray
+            #   wf_shade : shading gather 588 + path state 128 per closest ray (+ 48 B/pixel/spp lives in raygen/resolve)
+            #   wf_shadow: 36 + 32n+48t per shadow ray
+            classes = {
+                "wf_extend": (st.traceKernelMs, st.traceKernelLaunches, r0_closest * (52.0 + 32.0 * n_c + 48.0 * t_c)),
+                "wf_shade": (st.shadeKernelMs, st.shadeKernelLaunches, r0_closest * (588.0 + 128.0)),
+                "wf_shadow": (st.shadowKernelMs, st.shadowKernelLaunches, r0_shadow * b_shadow),
+            }
+            kernel = max(classes, key=lambda k: classes[k][0])
+            tot_ms, n_launch, bytes_per_step = classes[kernel]
+            launches = n_launch / args.steps
+            per_launch_bytes = bytes_per_step / launches
+            avg_ms = tot_ms / n_launch
+            kernel_times = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
+                                "algorithmic_GBps": v[2] / (v[0] / args.steps * 1e-3) / 1e9} for k, v in classes.items()}
         else:
             # megakernel: one launch per accumulation index does the whole dispatch
             launches = spp
             per_launch_bytes = step_bytes / spp
             avg_ms = st.lastRenderMs / spp
             kernel = "pt_megakernel"
+            kernel_times = None
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": None, "kernel": kernel, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                              "traffic": _pmc_traffic(kernel), "kernel": kernel, "kernels": kernel_times, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                               "algorithmic_bytes_per_launch": per_launch_bytes,
                               "bytes_per_closest_ray": b_closest, "bytes_per_shadow_ray": b_shadow,
                               "whole_step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -337,8 +337,11 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     memset(out, 0, sizeof *out);
     out->closestRays = h.closestRays; out->shadowRays = h.shadowRays; out->paths = h.paths;
     if (c->timed) { float ms = 0.0f; if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess) out->lastRenderMs = ms; }
-    wavefront_trace_timing(c->wf, &out->traceKernelMs, &out->traceKernelLaunches);
-    out->bvhNodeCount = c->bvhNodes; out->bvhTriangleCount = c->bvhTris;
+    wavefront_collect_timing(c->wf);
+    out->traceKernelMs = c->wf.kernelMs[0]; out->traceKernelLaunches = c->wf.kernelLaunches[0];
+    out->shadeKernelMs = c->wf.kernelMs[1]; out->shadeKernelLaunches = c->wf.kernelLaunches[1];
+    out->shadowKernelMs = c->wf.kernelMs[2]; out->shadowKernelLaunches = c->wf.kernelLaunches[2];
+    out->bvhNodeCount = c->bvhNodes; out->bvhTriangleCount = c->bvhTris; out->bvhMaxDepth = c->traits.bvhMaxDepth;
     return HRPT_OK;
 }
 

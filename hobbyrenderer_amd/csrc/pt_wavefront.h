@@ -23,10 +23,12 @@ struct SceneTraits {
 struct WavefrontState {
     void* pool = nullptr;              // one device allocation carved into the SoA queues
     size_t poolBytes = 0;
-    std::vector<hipEvent_t> events;    // start/stop pairs around every closest-hit trace launch
+    // start/stop event pairs around every extend / shade / shadow launch; kind[i] = 0,1,2
+    std::vector<hipEvent_t> events;
+    std::vector<uint8_t> kind;
     uint32_t eventsUsed = 0;
-    float traceMs = 0.0f;              // summed device time of wf_extend since the last reset
-    uint32_t traceLaunches = 0;
+    float kernelMs[3] = { 0.0f, 0.0f, 0.0f };      // summed device time per kernel class since the last reset
+    uint32_t kernelLaunches[3] = { 0, 0, 0 };
     // tuning knobs (0 = default)
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
@@ -38,7 +40,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
                             uint32_t accumCount, float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
                             DeviceCounters* counters, hipStream_t stream, std::string& error);
 void wavefront_release(WavefrontState& st);
-void wavefront_trace_timing(WavefrontState& st, float* ms, uint32_t* launches);   // call after the stream is synchronised
+void wavefront_collect_timing(WavefrontState& st);   // call after the stream is synchronised; folds pending events into kernelMs
 void wavefront_reset_timing(WavefrontState& st);
 
 } // namespace hrt

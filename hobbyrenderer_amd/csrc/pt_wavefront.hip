@@ -475,18 +475,37 @@ void wavefront_release(WavefrontState& st)
     st.events.clear(); st.eventsUsed = 0;
 }
 
-void wavefront_trace_timing(WavefrontState& st, float* ms, uint32_t* launches)
+void wavefront_collect_timing(WavefrontState& st)
 {
-    // called after the stream has been synchronised
-    if (st.eventsUsed) {
-        float total = 0.0f;
-        for (uint32_t i = 0; i + 1 < st.eventsUsed; i += 2) { float t = 0.0f; if (hipEventElapsedTime(&t, st.events[i], st.events[i + 1]) == hipSuccess) total += t; }
-        st.traceMs += total; st.traceLaunches += st.eventsUsed / 2; st.eventsUsed = 0;
+    for (uint32_t i = 0; i + 1 < st.eventsUsed; i += 2) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, st.events[i], st.events[i + 1]) == hipSuccess) { st.kernelMs[st.kind[i / 2]] += t; st.kernelLaunches[st.kind[i / 2]]++; }
     }
-    *ms = st.traceMs; *launches = st.traceLaunches;
+    st.eventsUsed = 0;
 }
 
-void wavefront_reset_timing(WavefrontState& st) { st.traceMs = 0.0f; st.traceLaunches = 0; st.eventsUsed = 0; }
+void wavefront_reset_timing(WavefrontState& st)
+{
+    st.eventsUsed = 0;
+    for (int k = 0; k < 3; ++k) { st.kernelMs[k] = 0.0f; st.kernelLaunches[k] = 0; }
+}
+
+namespace {
+// records an event; pairs are (begin, end) around one launch of kernel class `kind`
+bool timing_mark(WavefrontState& st, hipStream_t stream, int kind, bool begin)
+{
+    if (st.eventsUsed >= 4096) return true;   // a single render never needs more; stop timing rather than grow unbounded
+    if (st.eventsUsed + 1 > st.events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        st.events.push_back(e);
+    }
+    if (begin) { if (st.kind.size() < st.eventsUsed / 2 + 1) st.kind.resize(st.eventsUsed / 2 + 1); st.kind[st.eventsUsed / 2] = (uint8_t)kind; }
+    (void)hipEventRecord(st.events[st.eventsUsed], stream);
+    st.eventsUsed++;
+    return true;
+}
+}
 
 hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptPathTracerConstants& constants,
                             uint32_t accumCount, float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
@@ -571,15 +590,16 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const int maxBounces = (int)cb.m_MaxBounces;
         for (int bounce = 0; bounce < maxBounces; ++bounce) {
             const uint32_t parity = (uint32_t)bounce & 1u;
-            if (st.eventsUsed + 2 > st.events.size()) { hipEvent_t e0, e1; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { error = "hipEventCreate"; return hipErrorOutOfMemory; } st.events.push_back(e0); st.events.push_back(e1); }
-            (void)hipEventRecord(st.events[st.eventsUsed], stream);
+            const bool timed = st.eventsUsed + 6 <= 4096;
+            if (timed) timing_mark(st, stream, 0, true);
             launch_extend(v, dim3(grid), traceLds, stream, a, parity);
-            (void)hipEventRecord(st.events[st.eventsUsed + 1], stream);
-            st.eventsUsed += 2;
+            if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             launch_shadow(v, dim3(grid), traceLds, stream, a, bounce);
+            if (timed) timing_mark(st, stream, 2, false);
         }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;
         hipLaunchKernelGGL(wf_resolve, dim3(rgrid), dim3(kBlock), 0, stream, a, accumulation, output, cb.m_AccumulationIndex);

@@ -15,6 +15,15 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make -C hobbyrenderer_amd/csrc` (or __graft_entry__.build()). "
         "The HIP library is the only backend of this package.")
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 (soname libamdhip64.so.7)
+# and RCCL is linked against it. If libhobbyrt_pt.so were loaded first it would pull /opt/rocm's copy in as a SECOND
+# runtime, and whichever initialises the GPU second then finds no device. Importing torch first makes the dynamic
+# loader satisfy our DT_NEEDED libamdhip64.so.7 with the already loaded copy. Without torch the ROCm copy is used.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pure-ctypes use (no multi-GPU): /opt/rocm's runtime through the library's RUNPATH
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 EXPORTS = [

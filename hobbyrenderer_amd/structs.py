@@ -80,7 +80,9 @@ class DeviceDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("closestRays", C.c_uint64), ("shadowRays", C.c_uint64), ("paths", C.c_uint64),
                 ("lastRenderMs", C.c_float), ("traceKernelMs", C.c_float), ("traceKernelLaunches", C.c_uint32),
-                ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("pad", C.c_uint32)]
+                ("shadeKernelMs", C.c_float), ("shadeKernelLaunches", C.c_uint32),
+                ("shadowKernelMs", C.c_float), ("shadowKernelLaunches", C.c_uint32),
+                ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("bvhMaxDepth", C.c_uint32)]
 
 
 def default_material():

@@ -223,11 +223,17 @@ typedef struct HrptStats {
     uint64_t shadowRays;                   /* CalculateRTShadow queries launched */
     uint64_t paths;                        /* pixel-paths started */
     float    lastRenderMs;                 /* device time of the last hrpt_render (HIP events on the context stream) */
-    float    traceKernelMs;                /* summed device time of the dominant (trace) kernel in the last render */
+    /* summed device time / launch count per kernel class of the wavefront pipeline since hrpt_reset_stats
+     * (HIP events recorded on the context stream around every launch); zero in megakernel mode */
+    float    traceKernelMs;                /* wf_extend: closest-hit traversal */
     uint32_t traceKernelLaunches;
+    float    shadeKernelMs;                /* wf_shade: attributes, BSDF, NEE sample generation, compaction */
+    uint32_t shadeKernelLaunches;
+    float    shadowKernelMs;               /* wf_shadow: NEE visibility */
+    uint32_t shadowKernelLaunches;
     uint32_t bvhNodeCount;
     uint32_t bvhTriangleCount;
-    uint32_t pad;
+    uint32_t bvhMaxDepth;
 } HrptStats;
 
 typedef struct HrptContext HrptContext;

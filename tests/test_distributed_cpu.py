@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the N>1 path: band sharding + the single all-gather + resolve reproduce the
+single-rank image bit for bit. The renderer behind the sharding logic is the CPU oracle here (no GPU in this
+suite); on GPUs bench.py drives the same hobbyrenderer_amd.distributed functions with the HIP path and RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, w, h, spp, bounces, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hobbyrenderer_amd import native, scenes
+    from hobbyrenderer_amd.distributed import render_sharded
+    from oracle.binding import Oracle
+    luts = native.precompute_atmosphere(2)
+    sc, view, pos, _ = scenes.config_cornell(luts, w, h)
+    o = Oracle(sc)
+    acc = np.zeros((h, w, 4), np.float32)
+    out = np.zeros((h, w, 4), np.float32)
+
+    def render_band(y0, y1):
+        for k in range(spp):
+            o.render(scenes.fill_constants(view, pos, sc, k, bounces), acc, out, (0, y0, w, y1), nthreads=2)
+
+    full = torch.from_numpy(acc)
+    render_sharded(render_band, full, rank, world, lambda f, b: dist.all_gather_into_tensor(f, b))
+    np.save(os.path.join(out_dir, f"acc_{rank}.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_sharding_matches_single_rank(tmp_path, luts):
+    from hobbyrenderer_amd import scenes
+    from oracle.binding import Oracle
+    w, h, spp, bounces = 64, 36, 2, 4
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(2, port, w, h, spp, bounces, str(tmp_path)), nprocs=2, join=True)
+    sc, view, pos, _ = scenes.config_cornell(luts, w, h)
+    o = Oracle(sc)
+    ref, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), w, h, spp)
+    a0 = np.load(tmp_path / "acc_0.npy"); a1 = np.load(tmp_path / "acc_1.npy")
+    assert np.array_equal(a0.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(a1.view(np.uint32), ref.view(np.uint32))
+
+
+def test_band_for_rank():
+    from hobbyrenderer_amd.distributed import band_for_rank
+    assert [band_for_rank(1080, 8, r) for r in range(8)] == [(135 * r, 135 * (r + 1)) for r in range(8)]
+    with pytest.raises(ValueError):
+        band_for_rank(1080, 7, 0)

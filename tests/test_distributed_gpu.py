@@ -1,0 +1,50 @@
+"""GPU plumbing of the N>1 path that can be exercised on a one-GPU box: the zero-copy torch view of the
+library-owned accumulation image and an RCCL (backend "nccl") all-gather through hobbyrenderer_amd.distributed
+with world_size 1. The 2/4/8-GPU runs are the driver's (bench.py --gpus N)."""
+import os
+
+import numpy as np
+import pytest
+
+from hobbyrenderer_amd import scenes, structs as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_tensor_view_and_rccl_allgather(luts):
+    import torch
+    import torch.distributed as dist
+    from hobbyrenderer_amd.distributed import device_tensor, render_sharded
+    from hobbyrenderer_amd.native import PathTracerContext
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sc, view, pos, cfg = scenes.config_cornell(luts, 128, 72)
+        ctx = PathTracerContext(0)
+        ctx.upload_scene(sc); ctx.resize(128, 72)
+        cb = scenes.fill_constants(view, pos, sc, 0, 4)
+        accum_ptr, out_ptr = ctx.device_images()
+        full = device_tensor(accum_ptr, (72, 128, 4), dev)
+
+        def render_band(y0, y1):
+            ctx.render(cb, accum_count=2, tile=(0, y0, 128, y1))
+            ctx.synchronize()
+
+        # world 1 through the collective branch: band == whole image
+        render_band(0, 72)
+        band = full.clone()
+        dist.all_gather_into_tensor(full, band)
+        torch.cuda.synchronize(dev)
+        ctx.resolve_output()
+        host = ctx.read_accumulation()
+        assert np.array_equal(full.cpu().numpy().view(np.uint32), host.view(np.uint32))
+        assert (host[..., 3] == 2).all()
+        y0, y1 = render_sharded(lambda a, b: None, full, 0, 1, dist.all_gather_into_tensor)
+        assert (y0, y1) == (0, 72)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
