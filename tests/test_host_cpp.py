@@ -1,0 +1,57 @@
+"""The C++ host side (include/hobbyrt/*.h, csrc/host/*): the reference's plugin surface and Scene structs.
+CPU: the C++ procedural scenes produce the same boundary inputs as the Python harness. GPU: the demo driver goes
+through RendererRegistry -> PathTracerRenderer::Setup/Render -> C ABI and its images equal the oracle's on the SAME bytes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hobbyrenderer_amd import scenes, structs as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "hobbyrenderer_amd", "hobbyrt_pt_demo")
+
+
+def _dump(tmp_path, scene, w, h, extra=()):
+    prefix = str(tmp_path / scene)
+    subprocess.check_call([DEMO, "--scene", scene, "--width", str(w), "--height", str(h), "--dump", "--out", prefix, *extra])
+    load = lambda name, dt: np.fromfile(prefix + "_" + name + ".bin", dt)
+    return dict(vertices=load("vertices", S.VertexQuantized), indices=load("indices", np.uint32), meshdata=load("meshdata", S.MeshData),
+                instances=load("instances", S.PerInstanceData), materials=load("materials", S.MaterialConstants), lights=load("lights", S.GPULight),
+                view=load("view", S.PlanarViewConstants)[0], misc=load("misc", np.float32)), prefix
+
+
+@pytest.mark.parametrize("scene,w,h", [("cube", 64, 64), ("cornell", 64, 36)])
+def test_cpp_scene_matches_python_scene(tmp_path, luts, scene, w, h):
+    d, _ = _dump(tmp_path, scene, w, h, ("--no-gpu",))
+    sc, view, pos, _ = scenes.config_cube(luts, w) if scene == "cube" else scenes.config_cornell(luts, w, h)
+    assert d["vertices"].tobytes() == sc.vertices.tobytes()
+    assert np.array_equal(d["indices"], sc.indices)
+    assert d["meshdata"].tobytes() == sc.mesh_data.tobytes()
+    assert d["materials"].tobytes() == sc.materials.tobytes()
+    assert len(d["instances"]) == len(sc.instances)
+    for k in ("m_World", "m_MaterialIndex", "m_MeshDataIndex", "m_LODIndex"):
+        assert np.array_equal(d["instances"][k], sc.instances[k]), k
+    assert len(d["lights"]) == len(sc.lights) == 1 and d["lights"]["m_Type"][0] == S.LIGHT_DIRECTIONAL
+    for k in ("m_Intensity", "m_Color", "m_Range", "m_Radius", "m_CosSunAngularRadius"):
+        assert np.array_equal(d["lights"][k], sc.lights[k]), k
+    assert np.allclose(d["misc"][:3], sc.sun_direction, atol=1e-7) and np.allclose(d["misc"][3:6], pos)
+    for k in ("m_MatClipToWorldNoOffset", "m_MatWorldToClipNoOffset", "m_ViewportSize", "m_ViewportSizeInv"):
+        assert np.allclose(d["view"][k], view[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,frames,bounces", [("cube", 96, 96, 1, 1), ("cornell", 128, 72, 3, 4)])
+def test_plugin_path_equals_oracle(tmp_path, luts, scene, w, h, frames, bounces):
+    from oracle.binding import Oracle
+    d, prefix = _dump(tmp_path, scene, w, h, ("--frames", str(frames), "--bounces", str(bounces)))
+    acc = np.fromfile(prefix + "_accumulation.bin", np.float32).reshape(h, w, 4)
+    out = np.fromfile(prefix + "_output.bin", np.float32).reshape(h, w, 4)
+    sc = S.SceneArrays(d["vertices"], d["indices"], d["meshdata"], d["instances"], d["materials"], d["lights"], luts, [None] * 11)
+    sc.sun_direction = d["misc"][:3].copy()
+    sc.sun_angular_size_deg = float(d["misc"][6])
+    o = Oracle(sc)
+    oacc, oout = o.render_accumulated(lambda i: scenes.fill_constants(d["view"], d["misc"][3:6], sc, i, bounces, frame_index=i), w, h, frames)
+    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(out.view(np.uint32), oout.view(np.uint32))
