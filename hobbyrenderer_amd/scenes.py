@@ -309,3 +309,223 @@ def config_cornell(luts, width=1920, height=1080, extra_lights=False):
     sc = cornell_scene(luts, extra_lights)
     view, pos = planar_view(width, height, position=(0.0, 1.0, -3.4), fov_y=math.radians(40.0), aspect=16.0 / 9.0)
     return sc, view, pos, dict(spp=8, max_bounces=4)
+
+
+# ----------------------------------------------------------------------------- vectorised mesh construction (configs 4, 5)
+def quantize_snorm_array(v, bits):
+    v = np.clip(np.asarray(v, f32), f32(-1.0), f32(1.0))
+    scale = f32((1 << (bits - 1)) - 1)
+    rnd = np.where(v >= 0, f32(0.5), f32(-0.5)).astype(f32)
+    return (v * scale + rnd).astype(f32).astype(np.int32)          # truncation toward zero like the C cast
+
+
+def quantize_half_array(v):
+    ui = np.asarray(v, f32).view(np.uint32).astype(np.int64)
+    s = (ui >> 16) & 0x8000
+    em = ui & 0x7FFFFFFF
+    h = (em - (112 << 23) + (1 << 12)) >> 13
+    h = np.where(em < (113 << 23), 0, h)
+    h = np.where(em >= (143 << 23), 0x7C00, h)
+    h = np.where(em > (255 << 23), 0x7E00, h)
+    return ((s | h) & 0xFFFF).astype(np.uint32)
+
+
+def quantize_vertices(pos, normal, uv, tangent, tangent_w=None):
+    """Vectorised QuantizeVertex (src/ProceduralDefaultCube.cpp:60-86) for (N,3),(N,3),(N,2),(N,3) float arrays."""
+    pos, normal, uv, tangent = (np.asarray(a, f32) for a in (pos, normal, uv, tangent))
+    n = len(pos)
+    tw = np.ones(n, f32) if tangent_w is None else np.asarray(tangent_w, f32)
+    out = np.zeros(n, S.VertexQuantized)
+    out["m_Pos"] = pos
+    qn = (quantize_snorm_array(normal, 10) + 511).astype(np.uint32)
+    out["m_Normal"] = qn[:, 0] | (qn[:, 1] << 10) | (qn[:, 2] << 20) | np.where(tw >= 0, 0, 1 << 30).astype(np.uint32)
+    out["m_Uv"] = quantize_half_array(uv[:, 0]) | (quantize_half_array(uv[:, 1]) << 16)
+    tx, ty, tz = tangent[:, 0], tangent[:, 1], tangent[:, 2]
+    tsum = (np.abs(tx) + np.abs(ty)).astype(f32) + np.abs(tz)
+    ok = tsum > 1e-6
+    safe = np.where(ok, tsum, f32(1.0))
+    ax, ay = (tx / safe).astype(f32), (ty / safe).astype(f32)
+    tu = np.where(tz >= 0, ax, ((f32(1.0) - np.abs(ay)).astype(f32) * np.where(tx >= 0, f32(1.0), f32(-1.0))).astype(f32))
+    tv = np.where(tz >= 0, ay, ((f32(1.0) - np.abs(ax)).astype(f32) * np.where(ty >= 0, f32(1.0), f32(-1.0))).astype(f32))
+    qt = ((quantize_snorm_array(tu, 8) + 127).astype(np.uint32) | ((quantize_snorm_array(tv, 8) + 127).astype(np.uint32) << 8))
+    out["m_Tangent"] = np.where(ok, qt, 0).astype(np.uint32)
+    return out
+
+
+def _grid_indices(nu, nv):
+    """Two CCW-from-outside (LH) triangles per cell of an (nv+1) x (nu+1) vertex grid."""
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv))
+    a = (j * (nu + 1) + i).ravel()
+    b, c, d = a + 1, a + nu + 2, a + nu + 1
+    return np.stack([a, b, c, a, c, d], 1).ravel().astype(np.uint32)
+
+
+def mesh_parametric(fn, nu, nv, flip=False):
+    """fn(u, v) -> (pos, normal, tangent) on the unit square; returns quantised vertices + indices."""
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1))
+    u, v = u.ravel(), v.ravel()
+    pos, nrm, tan = fn(u, v)
+    idx = _grid_indices(nu, nv)
+    if flip:
+        idx = idx.reshape(-1, 3)[:, ::-1].ravel()
+    return quantize_vertices(pos, nrm, np.stack([u, v], 1), tan), idx
+
+
+def mesh_sphere(n_lon=48, n_lat=24, radius=1.0):
+    def fn(u, v):
+        th, ph = 2.0 * math.pi * u, math.pi * v
+        n = np.stack([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)], 1)
+        t = np.stack([-np.sin(th), np.zeros_like(th), np.cos(th)], 1)
+        return radius * n, n, t
+    return mesh_parametric(fn, n_lon, n_lat)
+
+
+def mesh_cylinder(n_seg=48, n_ring=16, radius=0.5, height=1.0, bulge=0.0):
+    def fn(u, v):
+        th = 2.0 * math.pi * u
+        r = radius * (1.0 + bulge * np.sin(math.pi * v))
+        n = np.stack([np.cos(th), np.zeros_like(th), np.sin(th)], 1)
+        p = np.stack([r * np.cos(th), height * v, r * np.sin(th)], 1)
+        t = np.stack([-np.sin(th), np.zeros_like(th), np.cos(th)], 1)
+        return p, n, t
+    return mesh_parametric(fn, n_seg, n_ring, flip=True)
+
+
+def mesh_plane(nu=8, nv=8, uv_scale=1.0):
+    """Unit quad in XZ (y = 0) facing +Y, tessellated."""
+    def fn(u, v):
+        p = np.stack([u - 0.5, np.zeros_like(u), v - 0.5], 1)
+        n = np.tile(np.array([[0.0, 1.0, 0.0]]), (len(u), 1))
+        t = np.tile(np.array([[1.0, 0.0, 0.0]]), (len(u), 1))
+        return p, n, t
+    verts, idx = mesh_parametric(fn, nu, nv, flip=True)
+    if uv_scale != 1.0:
+        u, v = np.meshgrid(np.linspace(0.0, uv_scale, nu + 1), np.linspace(0.0, uv_scale, nv + 1))
+        verts["m_Uv"] = quantize_half_array(u.ravel()) | (quantize_half_array(v.ravel()) << 16)
+    return verts, idx
+
+
+def sigma_a_from_attenuation(distance, color):
+    """ComputeSigmaAFromAttenuation, src/SceneLoader.cpp:29-39."""
+    if distance <= 0.0 or distance >= np.finfo(np.float32).max / 2:
+        return (0.0, 0.0, 0.0)
+    return tuple(float(min(-math.log(max(c, 1e-6)) / distance, 100.0)) for c in color)
+
+
+def procedural_texture(rng, size, kind):
+    """RGBA8 procedural textures: value-noise albedo, 2-channel normal, ORM (G roughness, B metallic), emissive, alpha cut-outs."""
+    y, x = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    base = sum(np.sin(2 * math.pi * (fx * x + fy * y) + ph) for fx, fy, ph in rng.uniform(0, 6, (5, 3)).round(0) + [0, 0, 0.3]) / 5.0
+    t = np.zeros((size, size, 4), np.uint8)
+    if kind == "albedo":
+        col = rng.uniform(0.3, 0.9, 3)
+        for c in range(3):
+            t[..., c] = np.clip((col[c] * (0.75 + 0.25 * base)) * 255, 0, 255)
+        t[..., 3] = 255
+    elif kind == "normal":
+        gx, gy = np.gradient(base)
+        t[..., 0] = np.clip(128 + 900 * gx, 0, 255); t[..., 1] = np.clip(128 + 900 * gy, 0, 255); t[..., 2] = 255; t[..., 3] = 255
+    elif kind == "orm":
+        t[..., 0] = 255; t[..., 1] = np.clip((0.6 + 0.4 * base) * 255, 51, 255); t[..., 2] = 255 if rng.random() < 0.2 else 0; t[..., 3] = 255
+    elif kind == "emissive":
+        t[..., :3] = (np.clip(base, 0, 1)[..., None] * 255 * rng.uniform(0.5, 1.0, 3)).astype(np.uint8); t[..., 3] = 255
+    elif kind == "alpha":
+        t[..., :3] = (np.array([0.25, 0.6, 0.2]) * 255).astype(np.uint8)
+        t[..., 3] = np.where(np.hypot((x * 4) % 1 - 0.5, (y * 4) % 1 - 0.5) < 0.38, 255, 0)
+    return t
+
+
+def sponza_class_scene(luts, detail=1.0, tex_size=256, seed=7):
+    """BASELINE config 4 stand-in: an open colonnade -- tessellated floor, two rows of bulged columns,
+    back wall, lintels, MASK foliage quads -- ~100 k triangles at detail=1, 24 materials with procedural RGBA8
+    albedo / normal / ORM / emissive textures (roughness U[0.2,1], metallic on ~20 %, emissive on 2 materials), lit by
+    the default sun and the sky (not a closed room: exercises the miss path and the atmosphere LUTs)."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    seg, ring = max(8, int(48 * detail)), max(4, int(40 * detail))
+    column = b.add_mesh(*mesh_cylinder(seg, ring, 0.35, 4.0, 0.08))
+    floor = b.add_mesh(*mesh_plane(max(2, int(48 * detail)), max(2, int(48 * detail)), uv_scale=8.0))
+    wall = b.add_mesh(*mesh_plane(max(2, int(16 * detail)), max(2, int(16 * detail)), uv_scale=4.0))
+    beam = b.add_mesh(*generate_default_cube())
+    leaf = b.add_mesh(*mesh_plane(2, 2))
+    orb = b.add_mesh(*mesh_sphere(max(8, int(32 * detail)), max(4, int(16 * detail)), 0.3))
+    mats = []
+    for m in range(20):
+        ta, tn, tr = (b.add_texture(procedural_texture(rng, tex_size, k)) for k in ("albedo", "normal", "orm"))
+        mats.append(b.add_material(m_TextureFlags=S.TEXFLAG_ALBEDO | S.TEXFLAG_NORMAL | S.TEXFLAG_ROUGHNESS_METALLIC, m_AlbedoTextureIndex=ta,
+                                   m_NormalTextureIndex=tn, m_RoughnessMetallicTextureIndex=tr,
+                                   m_RoughnessMetallic=(float(rng.uniform(0.2, 1.0)), 0.0)))
+    emis = []
+    for m in range(2):
+        te = b.add_texture(procedural_texture(rng, tex_size, "emissive"))
+        emis.append(b.add_material(m_TextureFlags=S.TEXFLAG_EMISSIVE, m_EmissiveTextureIndex=te, m_EmissiveFactor=(6.0, 4.0, 2.0, 1),
+                                   m_BaseColor=(0.8, 0.8, 0.8, 1)))
+    talpha = b.add_texture(procedural_texture(rng, tex_size, "alpha"))
+    foliage = [b.add_material(m_TextureFlags=S.TEXFLAG_ALBEDO, m_AlbedoTextureIndex=talpha, m_AlphaMode=S.ALPHA_MODE_MASK, m_AlphaCutoff=0.5,
+                              m_RoughnessMetallic=(0.8, 0.0)) for _ in range(2)]
+    b.add_instance(floor, mats[0], _mat((24, 1, 12), None, (0, 0, 0)))
+    b.add_instance(wall, mats[1], _mat((24, 1, 6), _ROT_TO["-z"], (0, 3, 5.5)))
+    k = 2
+    for row, z in enumerate((-2.5, 2.5)):
+        for i in range(12):
+            x = -11.0 + 2.0 * i
+            b.add_instance(column, mats[k % 20], _mat((1, 1, 1), None, (x, 0, z))); k += 1
+        b.add_instance(beam, mats[k % 20], _mat((23.0, 0.5, 0.9), None, (0, 4.25, z))); k += 1
+    for i in range(16):
+        a = rng.uniform(0, 2 * math.pi)
+        rot = [[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]]
+        tilt = np.array(_ROT_TO["-z"], np.float64) @ np.array(rot)
+        b.add_instance(leaf, foliage[i % 2], _mat((1.2, 1, 1.2), tilt, (rng.uniform(-10, 10), rng.uniform(0.6, 2.5), rng.uniform(-1.5, 1.5))))
+    for i in range(4):
+        b.add_instance(orb, emis[i % 2], _mat((1, 1, 1), None, (-7.5 + 5.0 * i, 3.4, 0.0)))
+    return b.finalize(luts)
+
+
+def glass_stress_scene(luts, detail=1.0):
+    """BASELINE config 5 stand-in: the Cornell-class room with thick glass spheres (ior 1.33 / 1.5 / 2.4,
+    Beer-Lambert sigmaA from attenuationColor (0.9,0.3,0.3) @ 0.5 m), a rough glass slab, one thin-walled pane, lit by a
+    point light (radius 0.05), a spot light and the emissive quad; transmission and BLEND paths, shadow-ray volumes."""
+    b = SceneBuilder()
+    quad = b.add_mesh(*generate_floor_quad())
+    cube = b.add_mesh(*generate_default_cube())
+    sph = b.add_mesh(*mesh_sphere(max(8, int(64 * detail)), max(4, int(48 * detail)), 1.0))
+    white = b.add_material(m_BaseColor=(0.73, 0.73, 0.73, 1))
+    red = b.add_material(m_BaseColor=(0.65, 0.05, 0.05, 1))
+    green = b.add_material(m_BaseColor=(0.12, 0.45, 0.15, 1))
+    light = b.add_material(m_BaseColor=(0.78, 0.78, 0.78, 1), m_EmissiveFactor=(17, 12, 4, 1))
+    sig = sigma_a_from_attenuation(0.5, (0.9, 0.3, 0.3))
+    glass = [b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_TransmissionFactor=1.0, m_IOR=ior, m_RoughnessMetallic=(rough, 0.0),
+                            m_SigmaA=sig, m_AttenuationDistance=0.5, m_AttenuationColor=(0.9, 0.3, 0.3), m_BaseColor=(1, 1, 1, 1))
+             for ior, rough in ((1.33, 0.04), (1.5, 0.04), (2.4, 0.3))]
+    slab = b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_TransmissionFactor=0.9, m_IOR=1.5, m_RoughnessMetallic=(0.3, 0.0), m_BaseColor=(0.9, 0.95, 1.0, 1))
+    pane = b.add_material(m_AlphaMode=S.ALPHA_MODE_BLEND, m_TransmissionFactor=0.8, m_IOR=1.5, m_IsThinSurface=1, m_RoughnessMetallic=(0.04, 0.0),
+                          m_BaseColor=(0.8, 0.9, 1.0, 0.6))
+    zc, zl = -1.5, 5.0
+    b.add_instance(quad, white, _mat((2, 1, zl), _ROT_TO["+y"], (0, 0, zc)))
+    b.add_instance(quad, white, _mat((2, 1, zl), _ROT_TO["-y"], (0, 2, zc)))
+    b.add_instance(quad, red, _mat((2, 1, zl), _ROT_TO["+x"], (-1, 1, zc)))
+    b.add_instance(quad, green, _mat((2, 1, zl), _ROT_TO["-x"], (1, 1, zc)))
+    b.add_instance(quad, white, _mat((2, 1, 2), _ROT_TO["-z"], (0, 1, 1)))
+    b.add_instance(quad, white, _mat((2, 1, 2), _ROT_TO["+z"], (0, 1, -4)))
+    b.add_instance(quad, light, _mat((0.5, 1, 0.5), _ROT_TO["-y"], (0, 1.98, 0)))
+    for i, (g, x, r) in enumerate(zip(glass, (-0.55, 0.0, 0.55), (0.28, 0.33, 0.25))):
+        b.add_instance(sph, g, _mat((r, r, r), None, (x, r + 0.001, 0.1 - 0.25 * i)))
+    b.add_instance(cube, slab, _mat((0.9, 0.5, 0.08), None, (0.3, 0.25, -0.9)))
+    b.add_instance(quad, pane, _mat((0.8, 1, 0.9), _ROT_TO["-z"], (-0.45, 0.55, -0.7)))
+    b.add_light(S.LIGHT_POINT, position=(0.5, 1.6, -0.8), color=(1.0, 0.95, 0.9), intensity=2.5, radius=0.05, range_=12.0)
+    b.add_light(S.LIGHT_SPOT, position=(-0.6, 1.85, -1.2), direction=(0.35, -1.0, 0.55), color=(0.7, 0.8, 1.0), intensity=8.0, radius=0.02,
+                inner=0.35, outer=0.7)
+    return b.finalize(luts)
+
+
+def config_sponza_class(luts, width=1920, height=1080, detail=1.0, tex_size=256):
+    sc = sponza_class_scene(luts, detail, tex_size)
+    view, pos = planar_view(width, height, position=(-9.0, 1.7, -0.4), yaw=math.radians(78.0), pitch=math.radians(-3.0), fov_y=math.radians(55.0),
+                            aspect=16.0 / 9.0)
+    return sc, view, pos, dict(spp=8, max_bounces=8)
+
+
+def config_glass(luts, width=1920, height=1080, detail=1.0):
+    sc = glass_stress_scene(luts, detail)
+    view, pos = planar_view(width, height, position=(0.0, 1.0, -3.4), fov_y=math.radians(40.0), aspect=16.0 / 9.0)
+    return sc, view, pos, dict(spp=64, max_bounces=12)

@@ -138,3 +138,20 @@ def test_error_paths(ctx, luts):
     ctx.upload_scene(sc)   # context still usable
     ctx.render(scenes.fill_constants(view, pos, sc, 0, 1))
     assert np.isfinite(ctx.read_output()).all()
+
+
+# ---- BASELINE configs 4 and 5 (stand-in scenes) at sizes the oracle finishes in seconds ---------
+@pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
+def test_config4_sponza_class_reduced(ctx, luts, flags):
+    """~100 k world triangles (BVH in HBM/L2, 32-deep LDS stack), textured PBR + MASK foliage + emissive, open sky."""
+    sc, view, pos, cfg = scenes.config_sponza_class(luts, 160, 90, detail=1.0, tex_size=64)
+    res = _run_both(ctx, sc, view, pos, 160, 90, 2, cfg["max_bounces"], flags)
+    assert res[2].bvhTriangleCount > 90000
+    _assert_parity(*res)
+
+
+@pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
+def test_config5_glass_stress_reduced(ctx, luts, flags):
+    """Thick glass (IOR 1.33/1.5/2.4, Beer-Lambert), rough slab, thin pane, point + spot + sun, 12 bounces."""
+    sc, view, pos, cfg = scenes.config_glass(luts, 160, 90, detail=0.5)
+    _assert_parity(*_run_both(ctx, sc, view, pos, 160, 90, 4, cfg["max_bounces"], flags))
