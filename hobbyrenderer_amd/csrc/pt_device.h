@@ -684,27 +684,27 @@ HRT_DEV f3 normal_with_tbn(float nx, float ny, f3 normal, f3 tangent, float tang
     return normalize(o);
 }
 // GetPBRAttributes, RaytracingCommon.hlsli:252-296
-HRT_DEV Pbr pbr_attributes(const SceneView& s, const SurfaceAttr& a, const HrptMaterialConstants& m)
+HRT_DEV Pbr pbr_attributes(const SceneView& s, const SurfaceAttr& a, const HrptMaterialConstants& m, uint32_t texFlags)
 {
     Pbr p;
     p.baseColor = mk3(m.m_BaseColor); p.alpha = m.m_BaseColor[3];
-    if (m.m_TextureFlags & HRPT_TEXFLAG_ALBEDO) {
+    if (texFlags & HRPT_TEXFLAG_ALBEDO) {
         f4 t = sample_texture(s, m.m_AlbedoTextureIndex, m.m_AlbedoSamplerIndex, a.uv);
         p.baseColor = p.baseColor * mk3(t.x, t.y, t.z); p.alpha *= t.w;
     }
     p.roughness = m.m_RoughnessMetallic[0];
     p.metallic = m.m_RoughnessMetallic[1];
-    if (m.m_TextureFlags & HRPT_TEXFLAG_ROUGHNESS_METALLIC) {
+    if (texFlags & HRPT_TEXFLAG_ROUGHNESS_METALLIC) {
         f4 t = sample_texture(s, m.m_RoughnessMetallicTextureIndex, m.m_RoughnessSamplerIndex, a.uv);
         p.roughness = t.y; p.metallic = t.z;
     }
     p.roughness = hrt_max(p.roughness, 0.04f);
     p.emissive = mk3(m.m_EmissiveFactor);
-    if (m.m_TextureFlags & HRPT_TEXFLAG_EMISSIVE) {
+    if (texFlags & HRPT_TEXFLAG_EMISSIVE) {
         f4 t = sample_texture(s, m.m_EmissiveTextureIndex, m.m_EmissiveSamplerIndex, a.uv);
         p.emissive = p.emissive * mk3(t.x, t.y, t.z);
     }
-    if (m.m_TextureFlags & HRPT_TEXFLAG_NORMAL) {
+    if (texFlags & HRPT_TEXFLAG_NORMAL) {
         f4 t = sample_texture(s, m.m_NormalTextureIndex, m.m_NormalSamplerIndex, a.uv);
         p.normal = normal_with_tbn(t.x, t.y, a.worldNormal, a.worldTangent, a.tangentSign);
     } else p.normal = normalize(a.worldNormal);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerC
                 SurfaceCarry carry;
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 f3 neeThroughput;
-                SurfaceOutcome oc = shade_surface_a(s, cb, ps, hit, carry, [&](uint32_t, f3 worldPos, f3 L, float maxDist, f3 dif, f3 spec) {
+                SurfaceOutcome oc = shade_surface_a<true, true, false>(s, cb, ps, hit, carry, [&](uint32_t, f3 worldPos, f3 L, float maxDist, f3 dif, f3 spec) {
                     ++nShadow;
                     float shadow = shadow_query(s, bvh, worldPos, L, maxDist, stack);
                     totalDiffuse = totalDiffuse + dif * shadow;

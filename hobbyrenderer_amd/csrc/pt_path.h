@@ -131,11 +131,13 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
 // One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908): early-outs, the jittered sample
 // (2 RNG draws when reached), per-sample byproducts and the unshadowed EvaluateDirectLight terms.
 // Returns false when the light contributes nothing and casts no shadow ray.
+// DIRONLY: the scene's light list is known to hold directional lights only (point/spot code compiled out).
+template <bool DIRONLY>
 HRT_DEV bool nee_sample(const SceneView& s, const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunDirection, float sunIntensity, float cosSun,
                         uint32_t& rng, f3& L, float& maxDist, f3& diffuse, f3& specular)
 {
     f3 radiance;
-    if (l.m_Type == HRPT_LIGHT_DIRECTIONAL) {                                   // :716-745
+    if (DIRONLY || l.m_Type == HRPT_LIGHT_DIRECTIONAL) {                        // :716-745
         if (dot(in.N, sunDirection) <= 0.0f) return false;
         // inputs.sunRadiance (PathTracer.hlsl:137) is a pure function of the hit position and is only read past this
         // early-out, so it is evaluated here (one transmittance-LUT fetch) instead of for every hit.
@@ -143,7 +145,7 @@ HRT_DEV bool nee_sample(const SceneView& s, const HrptGPULight& l, Lighting in, 
         float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
         L = sample_cone(sunDirection, cosSun, ux, uy);
         maxDist = 1e10f;
-    } else if (l.m_Type == HRPT_LIGHT_POINT || l.m_Type == HRPT_LIGHT_SPOT) {   // :752-804, :809-874
+    } else if (!DIRONLY && (l.m_Type == HRPT_LIGHT_POINT || l.m_Type == HRPT_LIGHT_SPOT)) {   // :752-804, :809-874
         if (l.m_Intensity <= 0.0f) return false;
         f3 lp = mk3(l.m_Position);
         f3 toLight = lp - worldPos;
@@ -187,22 +189,26 @@ enum SurfaceOutcome { SURFACE_TRANSMITTED = 0, SURFACE_SCATTER = 1 };
 
 // PathTracer.hlsl:92-261 up to the light loop. EMIT(lightOrdinal, worldPos, L, maxDist, diffuse, specular) receives
 // each light sample; the caller owes  radiance += neeThroughput * (sum(diffuse_i*shadow_i) + (bounce==0 ? sum(specular_i*shadow_i) : 0)).
-template <class EMIT>
+// Compile-time scene traits (all-true / DIRONLY=false is the general form and always correct):
+//   TEX     some material samples a texture          (false: every m_TextureFlags is 0 -> sampling code compiled out)
+//   TRANS   some material is transmissive or BLEND   (false: the transmission branch :149-255 is compiled out)
+//   DIRONLY every light is directional               (true: point / spot code compiled out)
+template <bool TEX, bool TRANS, bool DIRONLY, class EMIT>
 HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, const Hit& hit,
                                        SurfaceCarry& carry, EMIT&& emit)
 {
     TriVerts tv = load_tri_attr(s, hit.tri);                                      // inst/mesh/vertex fetch :92-94,:104 (LOD 0, :103)
     GpuInstShade is = s.instShade[tv.inst];
     const HrptMaterialConstants& mat = s.materials[tv.material];
-    uint32_t texFlags = mat.m_TextureFlags;
+    uint32_t texFlags = TEX ? mat.m_TextureFlags : 0u;
 
-    if (ps.inVolume) {                                                            // Beer-Lambert :97-100
+    if (TRANS && ps.inVolume) {                                                            // Beer-Lambert :97-100
         f3 tr = mk3(hrt_exp(-(ps.sigmaA.x + ps.sigmaS.x) * hit.t), hrt_exp(-(ps.sigmaA.y + ps.sigmaS.y) * hit.t),
                     hrt_exp(-(ps.sigmaA.z + ps.sigmaS.z) * hit.t));
         ps.throughput = ps.throughput * tr;
     }
     SurfaceAttr attr = full_hit_attributes(s, hit, ps.ray, tv, is, (texFlags & HRPT_TEXFLAG_NORMAL) != 0);
-    Pbr pbr = pbr_attributes(s, attr, mat);
+    Pbr pbr = pbr_attributes(s, attr, mat, texFlags);
 
     f3 Ng = normalize(attr.worldNormal);
     f3 N = pbr.normal;
@@ -218,7 +224,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     in.roughness = pbr.roughness; in.metallic = pbr.metallic; in.ior = mat.m_IOR;
     prepare_byproducts(in);                                                       // :142 (L = 0 => H = V)
 
-    if (mat.m_TransmissionFactor > 0.0f || mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {    // :149-255
+    if (TRANS && (mat.m_TransmissionFactor > 0.0f || mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND)) {    // :149-255
         float effectiveAlpha = (mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) ? pbr.alpha : 1.0f;
         float transmissionFactor = hrt_max(mat.m_TransmissionFactor, 1.0f - effectiveAlpha);
         float materialIOR = hrt_max(mat.m_IOR, 1.0001f);
@@ -267,7 +273,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
         HrptGPULight l;
         if (i < s.lightCount) l = s.lights[i]; else { l = HrptGPULight(); l.m_Type = 0; }   // OOB structured read = zeros
         f3 L, dif, spec; float maxDist;
-        if (nee_sample(s, l, in, attr.worldPos, sunDir, sunIntensity, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
+        if (nee_sample<DIRONLY>(s, l, in, attr.worldPos, sunDir, sunIntensity, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
             emit(i, attr.worldPos, L, maxDist, dif, spec);
     }
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;

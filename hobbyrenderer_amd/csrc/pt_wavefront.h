@@ -17,6 +17,9 @@ struct SceneView;
 struct SceneTraits {
     bool hasMedium = false;            // a thick (non-thin) transmissive material exists: interior IOR/sigma travel with the path
     bool hasStochasticAlpha = false;   // a non-transmissive BLEND material exists: TraceRayStandard draws RNG (RaytracingCommon.hlsli:181)
+    bool hasTextures = false;          // some instanced material has m_TextureFlags != 0
+    bool hasTransmissiveOrBlend = false;   // some instanced material takes the transmission branch (PathTracer.hlsl:149)
+    bool directionalLightsOnly = true; // every GPULight is type 0
     uint32_t bvhMaxDepth = 0;
 };
 
@@ -33,6 +36,7 @@ struct WavefrontState {
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
     bool forceGlobalBvh = false;
+    bool forceGeneralShade = false;
 };
 
 bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& constants);

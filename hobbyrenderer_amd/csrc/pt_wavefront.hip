@@ -273,7 +273,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 template <int MAXL>
 struct NeeBuf { f3 L[MAXL]; float maxDist[MAXL]; f3 dif[MAXL], spec[MAXL]; };
 
-template <int MAXL>
+// SIMPLE: scene traits proven at upload -- no textures, no transmissive / BLEND material, directional lights only --
+// compile the corresponding branches out (the general variant is always correct).
+template <int MAXL, bool SIMPLE>
 __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                     Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
                     SurfaceCarry carry;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
-                    SurfaceOutcome oc = shade_surface_a(s, cb, ps, h, carry, [&](uint32_t, f3 wp, f3 L, float maxDist, f3 dif, f3 spec) {
+                    SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t, f3 wp, f3 L, float maxDist, f3 dif, f3 spec) {
                         if (nNee < (uint32_t)MAXL) {
                             worldPos = wp;
                             nee.L[nNee] = L; nee.maxDist[nNee] = maxDist; nee.dif[nNee] = dif; nee.spec[nNee] = spec;
@@ -572,6 +574,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 8;
 
     const bool manyLights = maxLights > 1;
+    const bool simpleScene = !traits.hasTextures && !traits.hasTransmissiveOrBlend && traits.directionalLightsOnly && !st.forceGeneralShade;
     for (uint32_t first = 0; first < accumCount; first += sppPerBatch) {
         const uint32_t spp = (accumCount - first) < sppPerBatch ? (accumCount - first) : sppPerBatch;
         a.spp = spp; a.numSamples = (uint32_t)(pixelsPadded * spp);
@@ -595,8 +598,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             launch_extend(v, dim3(grid), traceLds, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
-            if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
-            else hipLaunchKernelGGL((wf_shade<1>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             launch_shadow(v, dim3(grid), traceLds, stream, a, bounce);
             if (timed) timing_mark(st, stream, 2, false);
