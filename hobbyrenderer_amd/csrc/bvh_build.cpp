@@ -160,7 +160,8 @@ inline void unpack_tangent(const HrptVertexQuantized& q, float* t)
 bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
 {
     out = BuiltBvh();
-    if (!s.vertices || !s.indices || !s.meshData || !s.instances || !s.materials || !s.lights) { error = "null scene array"; return false; }
+    if ((!s.vertices && s.vertexCount) || (!s.indices && s.indexCount) || (!s.meshData && s.meshDataCount) || (!s.instances && s.instanceCount) ||
+        (!s.materials && s.materialCount) || !s.lights) { error = "null scene array with a non-zero count"; return false; }
     if (s.lightCount == 0) { error = "scene needs at least one light (the reference guarantees a directional light, src/Scene.cpp:635-666)"; return false; }
     for (uint32_t i = 0; i < s.indexCount; ++i)
         if (s.indices[i] >= s.vertexCount) { error = "index buffer references a vertex out of range"; return false; }

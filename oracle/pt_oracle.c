@@ -226,7 +226,8 @@ void or_destroy(OrContext* c)
 
 OrContext* or_create(const HrptSceneDesc* s)
 {
-    if (!s || !s->vertices || !s->indices || !s->meshData || !s->instances || !s->materials || !s->lights ||
+    if (!s || (!s->vertices && s->vertexCount) || (!s->indices && s->indexCount) || (!s->meshData && s->meshDataCount) ||
+        (!s->instances && s->instanceCount) || (!s->materials && s->materialCount) || !s->lights ||
         !s->brunetonTransmittance || !s->brunetonScattering || s->lightCount == 0) { set_err("null scene array"); return NULL; }
     OrContext* c = (OrContext*)calloc(1, sizeof *c);
     c->vertices = dup_mem(s->vertices, (size_t)s->vertexCount * sizeof *s->vertices); c->vertexCount = s->vertexCount;

@@ -155,3 +155,52 @@ def test_config5_glass_stress_reduced(ctx, luts, flags):
     """Thick glass (IOR 1.33/1.5/2.4, Beer-Lambert), rough slab, thin pane, point + spot + sun, 12 bounces."""
     sc, view, pos, cfg = scenes.config_glass(luts, 160, 90, detail=0.5)
     _assert_parity(*_run_both(ctx, sc, view, pos, 160, 90, 4, cfg["max_bounces"], flags))
+
+
+# ---- edge cases: empty / tiny scenes, odd sizes, unaligned tiles, spp batching, big BVH -------------------------
+def _empty_scene(luts):
+    b = scenes.SceneBuilder()
+    b.add_mesh(*scenes.generate_default_cube())
+    b.add_material()
+    return b.finalize(luts)          # a mesh and a material but no instance: every ray misses
+
+
+def _one_triangle_scene(luts):
+    b = scenes.SceneBuilder()
+    v = np.array([scenes.quantize_vertex(p, (0, 0, -1), uv, (1, 0, 0), 1.0) for p, uv in
+                  (((-1, -1, 0), (0, 0)), ((0, 1.5, 0), (0.5, 1)), ((1, -1, 0), (1, 0)))], S.VertexQuantized)
+    m = b.add_mesh(v, np.array([0, 1, 2], np.uint32))
+    b.add_instance(m, b.add_material(m_BaseColor=(0.8, 0.7, 0.6, 1), m_RoughnessMetallic=(0.3, 1.0)))
+    return b.finalize(luts)
+
+
+@pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
+@pytest.mark.parametrize("builder", [_empty_scene, _one_triangle_scene], ids=["empty", "one_triangle"])
+def test_degenerate_scenes(ctx, luts, flags, builder):
+    sc = builder(luts)
+    view, pos = scenes.planar_view(53, 37)          # not multiples of 8: padded 8x8 sample tiles
+    _assert_parity(*_run_both(ctx, sc, view, pos, 53, 37, 2, 3, flags))
+
+
+def test_unaligned_tiles_and_spp_batches(ctx, luts):
+    """Tile rectangles not aligned to 8 pixels, and accumCount larger than one wavefront batch (64 indices)."""
+    from oracle.binding import Oracle
+    sc, view, pos, _ = scenes.config_cornell(luts, 45, 27)
+    ctx.upload_scene(sc); ctx.resize(45, 27)
+    spp = 70
+    for tile in ((0, 0, 13, 27), (13, 0, 45, 11), (13, 11, 45, 27)):
+        ctx.render(scenes.fill_constants(view, pos, sc, 0, 3), accum_count=spp, tile=tile)
+    acc = ctx.read_accumulation()
+    o = Oracle(sc)
+    oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, 3), 45, 27, spp)
+    o.close()
+    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+
+
+@pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
+def test_million_triangle_bvh(ctx, luts, flags):
+    """~1.1 M world triangles (deep BVH, 32-entry LDS stack, BVH streamed from HBM/L2)."""
+    sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=3.4, tex_size=32)
+    res = _run_both(ctx, sc, view, pos, 96, 54, 1, 6, flags)
+    assert res[2].bvhTriangleCount > 1000000 and res[2].bvhMaxDepth < 32
+    _assert_parity(*res)
