@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mode", choices=["default", "megakernel", "wavefront"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal only: all ranks share GPU 0 and the all-gather runs over gloo through host memory; the printed value is NOT a result")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json config: 2 = headline (Cornell-class), 4 = Sponza-class stand-in, 5 = glass stress stand-in")
     args = ap.parse_args()
@@ -72,9 +74,15 @@ def main():
     from hobbyrenderer_amd import native, scenes, structs as S
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
@@ -101,16 +109,31 @@ def main():
     accum_ptr, _ = ctx.device_images()
     full = device_tensor(accum_ptr, (H, W, 4), dev) if world > 1 else None
 
+    def all_gather(full_t, band_t):
+        if not rehearse:
+            dist.all_gather_into_tensor(full_t, band_t)          # RCCL over xGMI
+        else:                                                    # gloo through host memory (one-GPU rehearsal)
+            host = torch.empty(full_t.shape, dtype=full_t.dtype)
+            dist.all_gather_into_tensor(host, band_t.cpu())
+            full_t.copy_(host)
+
+    same_stream = world > 1 and not rehearse
+    if same_stream:
+        # render, band clone, RCCL all-gather and resolve are all ordered on torch's current stream: no host sync in a step
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
     def render_band(b0, b1):
         ctx.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags)
-        ctx.synchronize()                                       # library stream -> host; RCCL runs on torch's stream
+        if not same_stream:
+            ctx.synchronize()                                   # library stream -> host before the host-staged gather
 
     def step():
         if world == 1:
             ctx.render(cb, accum_count=spp, flags=flags)
         else:
-            render_sharded(render_band, full, rank, world, dist.all_gather_into_tensor)   # the single collective
-            torch.cuda.synchronize(dev)
+            render_sharded(render_band, full, rank, world, all_gather)                   # the single collective
+            if not same_stream:
+                torch.cuda.synchronize(dev)
             ctx.resolve_output()                                # Output = accum.rgb / accum.a on every rank
 
     def sync_all():
@@ -131,9 +154,19 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
+    # per-kernel-class device times: a few extra steps with HRPT_FRAME_PROFILE (events around every launch), outside the timed region
+    prof_steps = 0
+    if world == 1 and args.mode != "megakernel":
+        prof_steps = 3
+        ctx.reset_stats()
+        for _ in range(prof_steps):
+            ctx.render(cb, accum_count=spp, flags=flags | S.FRAME_PROFILE)
+        ctx.synchronize()
+        pst = ctx.stats()
 
-    tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(st.closestRays + st.shadowRays), float(st.closestRays), float(st.shadowRays)], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearse else dev
+    tm = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([float(st.closestRays + st.shadowRays), float(st.closestRays), float(st.shadowRays)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -147,7 +180,7 @@ def main():
             "metric": "Mrays/s at 1920x1080, 8 spp, 4 bounces; 1/2/4/8 GPU scaling",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not rehearse else "REHEARSAL on one GPU (gloo through host): not a result",
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
                        "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" if world > 1 else ""),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
@@ -180,24 +213,24 @@ def main():
         r0_closest, r0_shadow = float(st.closestRays) / args.steps, float(st.shadowRays) / args.steps   # rank 0, per step
         px0 = (y1 - y0) * W if world > 1 else W * H
         step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
-        if st.traceKernelLaunches > 0:
+        if prof_steps and pst.traceKernelLaunches > 0:
             # wavefront: per-class device time from HIP events the library records on ITS stream around every launch.
             # SURVEY 8(d) bytes split by the kernel that touches them (the three classes sum to B_closest / B_shadow):
             #   wf_extend: ray record 32 + traversal 32n+48t + hit record 20 per closest ray
             #   wf_shade : shading gather 588 + path state 128 per closest ray (+ 48 B/pixel/spp lives in raygen/resolve)
             #   wf_shadow: 36 + 32n+48t per shadow ray
             classes = {
-                "wf_extend": (st.traceKernelMs, st.traceKernelLaunches, r0_closest * (52.0 + 32.0 * n_c + 48.0 * t_c)),
-                "wf_shade": (st.shadeKernelMs, st.shadeKernelLaunches, r0_closest * (588.0 + 128.0)),
-                "wf_shadow": (st.shadowKernelMs, st.shadowKernelLaunches, r0_shadow * b_shadow),
+                "wf_extend": (pst.traceKernelMs, pst.traceKernelLaunches, r0_closest * (52.0 + 32.0 * n_c + 48.0 * t_c)),
+                "wf_shade": (pst.shadeKernelMs, pst.shadeKernelLaunches, r0_closest * (588.0 + 128.0)),
+                "wf_shadow": (pst.shadowKernelMs, pst.shadowKernelLaunches, r0_shadow * b_shadow),
             }
             kernel = max(classes, key=lambda k: classes[k][0])
             tot_ms, n_launch, bytes_per_step = classes[kernel]
-            launches = n_launch / args.steps
+            launches = n_launch / prof_steps
             per_launch_bytes = bytes_per_step / launches
             avg_ms = tot_ms / n_launch
-            kernel_times = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
-                                "algorithmic_GBps": v[2] / (v[0] / args.steps * 1e-3) / 1e9} for k, v in classes.items()}
+            kernel_times = {k: {"ms_per_step": v[0] / prof_steps, "launches_per_step": v[1] / prof_steps,
+                                "algorithmic_GBps": v[2] / (v[0] / prof_steps * 1e-3) / 1e9} for k, v in classes.items()}
         else:
             # megakernel: one launch per accumulation index does the whole dispatch
             launches = spp

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,6 +21,7 @@ using namespace hrt;
 struct HrptContext {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t ownStream = nullptr;         // created by hrpt_create; `stream` may be redirected by hrpt_set_stream
     std::string err;
     // scene
     std::vector<void*> allocations;          // scene-lifetime device allocations
@@ -107,12 +109,15 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     c->device = desc->deviceOrdinal;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
-        hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters)) != hipSuccess ||
-        hipMemset(c->dCounters, 0, sizeof(DeviceCounters)) != hipSuccess) {
+        hipMalloc((void**)&c->dCounters, sizeof(DeviceCounters) * kCounterShards) != hipSuccess ||
+        hipMemset(c->dCounters, 0, sizeof(DeviceCounters) * kCounterShards) != hipSuccess) {
         int r = fail(nullptr, HRPT_ERR_HIP, "hrpt_create: stream/event/counter creation failed");
         delete c;
         return r;
     }
+    c->ownStream = c->stream;
+    if (const char* e = getenv("HRPT_WF_SEGMENT_SHIFT")) c->wf.segmentShift = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     *out = c;
     return HRPT_OK;
 }
@@ -129,7 +134,7 @@ void hrpt_destroy(HrptContext* c)
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
 
@@ -264,6 +269,7 @@ int hrpt_render(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (wavefront) {
         std::string werr;
+        c->wf.profile = (p->flags & HRPT_FRAME_PROFILE) != 0;
         hipError_t e = wavefront_render(c->wf, c->view, c->traits, p->constants, p->accumCount, c->dAccum, c->dOutput, c->width, c->height, rect,
                                         c->dCounters, c->stream, werr);
         if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? HRPT_ERR_OUT_OF_MEMORY : HRPT_ERR_HIP, "wavefront_render: " + werr + ": " + hipGetErrorString(e));
@@ -278,6 +284,15 @@ int hrpt_render(HrptContext* c, const HrptFrameParams* p)
     }
     HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
     c->timed = true;
+    return HRPT_OK;
+}
+
+int hrpt_set_stream(HrptContext* c, void* hipStream, int useCallerStream)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = useCallerStream ? static_cast<hipStream_t>(hipStream) : c->ownStream;   // a NULL caller stream is the legacy default stream
     return HRPT_OK;
 }
 
@@ -335,10 +350,10 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     if (!out) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_stats: null out");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    DeviceCounters h{};
-    HIP_TRY(c, hipMemcpy(&h, c->dCounters, sizeof h, hipMemcpyDeviceToHost));
+    DeviceCounters h[kCounterShards];
+    HIP_TRY(c, hipMemcpy(h, c->dCounters, sizeof h, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
-    out->closestRays = h.closestRays; out->shadowRays = h.shadowRays; out->paths = h.paths;
+    for (int i = 0; i < kCounterShards; ++i) { out->closestRays += h[i].closestRays; out->shadowRays += h[i].shadowRays; out->paths += h[i].paths; }
     if (c->timed) { float ms = 0.0f; if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess) out->lastRenderMs = ms; }
     wavefront_collect_timing(c->wf);
     out->traceKernelMs = c->wf.kernelMs[0]; out->traceKernelLaunches = c->wf.kernelLaunches[0];
@@ -353,7 +368,7 @@ int hrpt_reset_stats(HrptContext* c)
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters) * kCounterShards, c->stream));
     wavefront_reset_timing(c->wf);
     return HRPT_OK;
 }

@@ -10,7 +10,8 @@ namespace hrt {
 
 struct SceneView;   // pt_device.h
 
-struct DeviceCounters {         // one instance in device memory per context
+constexpr int kCounterShards = 32;   // DeviceCounters[kCounterShards] per context; a block adds to shard blockIdx % kCounterShards
+struct DeviceCounters {         // 32 B; summed over the shards by hrpt_get_stats
     unsigned long long closestRays;
     unsigned long long shadowRays;
     unsigned long long paths;

@@ -72,9 +72,10 @@ __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerC
     }
     unsigned long long c = wave_sum(nClosest), sh = wave_sum(nShadow), pa = wave_sum(active ? 1u : 0u);
     if (threadIdx.x == 0) {
-        atomicAdd(&counters->closestRays, c);
-        atomicAdd(&counters->shadowRays, sh);
-        atomicAdd(&counters->paths, pa);
+        DeviceCounters* shard = counters + (blockIdx.x + blockIdx.y * gridDim.x) % kCounterShards;   // spread the tail atomics
+        atomicAdd(&shard->closestRays, c);
+        atomicAdd(&shard->shadowRays, sh);
+        atomicAdd(&shard->paths, pa);
     }
 }
 

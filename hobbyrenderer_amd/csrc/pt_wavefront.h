@@ -35,6 +35,8 @@ struct WavefrontState {
     // tuning knobs (0 = default)
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
+    bool profile = false;              // record HIP events around every extend / shade / shadow launch (HRPT_FRAME_PROFILE)
+    uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
     bool forceGlobalBvh = false;
     bool forceGeneralShade = false;
 };

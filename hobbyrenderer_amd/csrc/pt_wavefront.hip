@@ -28,7 +28,7 @@ namespace hrt {
 
 namespace {
 
-constexpr uint32_t kSegment = 1024;          // samples per wave-owned segment
+constexpr uint32_t kMaxSegment = 1024;       // samples per wave-owned segment: 2^segShift, 64..1024, chosen per batch
 constexpr uint32_t kBlock = 256;             // 4 waves
 constexpr uint32_t kMaxLights = 8;
 constexpr uint32_t kMaxSppPerBatch = 64;
@@ -46,6 +46,7 @@ struct WfBuffers {
 struct WfArgs {
     SceneView scene;
     WfBuffers b;
+    uint32_t segShift;         // log2(segment size)
     uint32_t numSegments;      // segments in this batch
     uint32_t numSamples;       // tilesX*tilesY*64*spp (padded to 8x8 pixel tiles)
     uint32_t pixelsPadded;     // tilesX*tilesY*64
@@ -101,6 +102,20 @@ HRT_DEV unsigned long long wave_sum_u32(unsigned int v)
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
 }
+// Statistics: one atomic per BLOCK on a counter shard (a returning-free add per wave on one word costs ~11 ns each and
+// serialises at the kernel tail: 8192 waves = ~0.1 ms per launch).
+HRT_DEV void block_count_add(unsigned long long* counterField0, size_t fieldOffsetWords, unsigned int perLane)
+{
+    __shared__ unsigned long long partial[kBlock / 64];
+    unsigned long long w = wave_sum_u32(perLane);
+    if (lane_id() == 0) partial[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (uint32_t i = 0; i < kBlock / 64; ++i) t += partial[i];
+        if (t) atomicAdd(counterField0 + (size_t)(blockIdx.x % kCounterShards) * (sizeof(DeviceCounters) / 8) + fieldOffsetWords, t);
+    }
+}
 
 // ------------------------------------------------------------------ raygen
 __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerConstants cb, JitterTable jt)
@@ -109,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nPaths = 0;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        uint32_t segBase = seg * kSegment, outCount = 0;
-        for (uint32_t base = 0; base < kSegment; base += 64) {
+        uint32_t segBase = seg << a.segShift, outCount = 0;
+        for (uint32_t base = 0; base < (1u << a.segShift); base += 64) {
             uint32_t smp = segBase + base + lane;
             bool active = smp < a.numSamples;
             uint32_t k = 0, px = 0, py = 0;
@@ -155,8 +170,7 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
         }
         if (lane == 0) a.b.pathCnt[0][seg] = outCount;
     }
-    unsigned long long np = wave_sum_u32(nPaths);
-    if (lane == 0 && np) atomicAdd(&a.counters->paths, np);
+    block_count_add(&a.counters->closestRays, 2, nPaths);
 }
 
 // ------------------------------------------------------------------ extend (closest hit)
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
     GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
     const SceneView& s = a.scene;
 
-    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t wavesPerBlock = kBlock / 64;
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     const float4* __restrict__ rayO = a.b.rayO[parity];
     float4* __restrict__ rayD = a.b.rayD[parity];
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
     const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
 
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.pathCnt[parity][seg], segBase = seg * kSegment;
+        const uint32_t cnt = a.b.pathCnt[parity][seg], segBase = seg << a.segShift;
         uint32_t next = 0;                       // wave-uniform: next ray of the segment to hand out
         // per-lane traversal state
         bool active = false;
@@ -265,8 +279,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             }
         }
     }
-    unsigned long long nr = wave_sum_u32(nRays);
-    if (lane == 0 && nr) atomicAdd(&a.counters->closestRays, nr);
+    block_count_add(&a.counters->closestRays, 0, nRays);
 }
 
 // ------------------------------------------------------------------ shade (+ compaction, + NEE sample emission)
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
     const uint32_t in = parity, out = parity ^ 1u;
     const SceneView& s = a.scene;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.pathCnt[in][seg], segBase = seg * kSegment;
+        const uint32_t cnt = a.b.pathCnt[in][seg], segBase = seg << a.segShift;
         uint32_t outCount = 0, shCount = 0;
         for (uint32_t base = 0; base < cnt; base += 64) {
             uint32_t i = base + lane;
@@ -383,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nRays = 0;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg * kSegment;
+        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift;
         for (uint32_t base = 0; base < cnt; base += 64) {
             uint32_t i = base + lane;
             if (i < cnt) {
@@ -415,8 +428,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
             }
         }
     }
-    unsigned long long nr = wave_sum_u32(nRays);
-    if (lane == 0 && nr) atomicAdd(&a.counters->shadowRays, nr);
+    block_count_add(&a.counters->closestRays, 1, nRays);
 }
 
 // ------------------------------------------------------------------ resolve: fold the indices in order (:332-339)
@@ -522,10 +534,10 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     uint32_t sppPerBatch = accumCount < kMaxSppPerBatch ? accumCount : kMaxSppPerBatch;
     const uint64_t maxSamples = st.maxSamplesPerBatch ? st.maxSamplesPerBatch : (64ull << 20);
     while (sppPerBatch > 1 && pixelsPadded * sppPerBatch > maxSamples) --sppPerBatch;
-    const uint64_t capacity = ((pixelsPadded * sppPerBatch + kSegment - 1) / kSegment) * kSegment;
+    const uint64_t capacity = ((pixelsPadded * sppPerBatch + kMaxSegment - 1) / kMaxSegment) * kMaxSegment;
     if (capacity >= (1ull << 31)) { error = "tile too large for one batch"; return hipErrorInvalidValue; }
     const uint32_t maxLights = constants.m_LightCount ? constants.m_LightCount : 1;
-    const uint32_t segs = (uint32_t)(capacity / kSegment);
+    const uint32_t segs = (uint32_t)(capacity / 64);   // counter arrays sized for the smallest segment
 
     // ---- pool layout
     size_t off = 0;
@@ -578,7 +590,14 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     for (uint32_t first = 0; first < accumCount; first += sppPerBatch) {
         const uint32_t spp = (accumCount - first) < sppPerBatch ? (accumCount - first) : sppPerBatch;
         a.spp = spp; a.numSamples = (uint32_t)(pixelsPadded * spp);
-        a.numSegments = (a.numSamples + kSegment - 1) / kSegment;
+        // segment size: large segments amortise the partially filled last iteration, small ones give every SIMD several
+        // waves when the batch is small (tile-sharded multi-GPU runs): aim for >= 4 waves per SIMD slot
+        // 256 measured best on MI355X for both the full 1080p x 8 spp batch and a 135-row band (scripts/seg_sweep.py)
+        uint32_t shift = st.segmentShift ? st.segmentShift : 8;
+        if (shift < 6) shift = 6;
+        if (shift > 10) shift = 10;
+        a.segShift = shift;
+        a.numSegments = (a.numSamples + (1u << shift) - 1) >> shift;
         const uint32_t wavesNeeded = a.numSegments, blocksNeeded = (wavesNeeded + 3) / 4;
         uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = blocksNeeded; if (grid == 0) grid = 1;
 
@@ -593,7 +612,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const int maxBounces = (int)cb.m_MaxBounces;
         for (int bounce = 0; bounce < maxBounces; ++bounce) {
             const uint32_t parity = (uint32_t)bounce & 1u;
-            const bool timed = st.eventsUsed + 6 <= 4096;
+            const bool timed = st.profile && st.eventsUsed + 6 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
             launch_extend(v, dim3(grid), traceLds, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }

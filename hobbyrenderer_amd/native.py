@@ -28,7 +28,7 @@ lib = C.CDLL(LIB_PATH)
 
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
-    "hrpt_synchronize", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
+    "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
     "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
@@ -42,6 +42,7 @@ lib.hrpt_upload_scene.argtypes = [C.c_void_p, C.POINTER(S.SceneDesc)]
 lib.hrpt_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
 lib.hrpt_render.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_synchronize.argtypes = [C.c_void_p]
+lib.hrpt_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.hrpt_get_device_images.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
 lib.hrpt_read_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_read_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -113,6 +114,14 @@ class PathTracerContext:
         p["tileX0"], p["tileY0"], p["tileX1"], p["tileY1"] = tile
         p["flags"] = flags
         self._check(lib.hrpt_render(self._h, p.ctypes.data))
+
+    def set_stream(self, hip_stream):
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream), or None to go
+        back to the context's own stream."""
+        if hip_stream is None:
+            self._check(lib.hrpt_set_stream(self._h, None, 0))
+        else:
+            self._check(lib.hrpt_set_stream(self._h, C.c_void_p(int(hip_stream)), 1))
 
     def synchronize(self):
         self._check(lib.hrpt_synchronize(self._h))

@@ -50,7 +50,7 @@ assert PathTracerConstants.fields["m_SunDirection"][1] == 752 and PathTracerCons
 TEXFLAG_ALBEDO, TEXFLAG_NORMAL, TEXFLAG_ROUGHNESS_METALLIC, TEXFLAG_EMISSIVE = 1, 2, 4, 8
 ALPHA_MODE_OPAQUE, ALPHA_MODE_MASK, ALPHA_MODE_BLEND = 0, 1, 2
 LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT = 0, 1, 2
-FRAME_DEFAULT, FRAME_MEGAKERNEL, FRAME_WAVEFRONT = 0, 1, 2
+FRAME_DEFAULT, FRAME_MEGAKERNEL, FRAME_WAVEFRONT, FRAME_PROFILE = 0, 1, 2, 4
 
 LUT_TRANSMITTANCE_SHAPE = (64, 256, 4)
 LUT_SCATTERING_SHAPE = (32, 128, 256, 4)

@@ -215,7 +215,8 @@ typedef struct HrptFrameParams {
 enum {
     HRPT_FRAME_DEFAULT = 0,
     HRPT_FRAME_MEGAKERNEL = 1,             /* one-thread-per-pixel restatement kernel (validation path) */
-    HRPT_FRAME_WAVEFRONT = 2               /* persistent wavefront pipeline (default when available) */
+    HRPT_FRAME_WAVEFRONT = 2,              /* persistent wavefront pipeline (default when available) */
+    HRPT_FRAME_PROFILE = 4                 /* record HIP events around every kernel launch: fills HrptStats::*KernelMs (adds launch gaps) */
 };
 
 typedef struct HrptStats {
@@ -251,6 +252,11 @@ int  hrpt_resize(HrptContext* ctx, uint32_t width, uint32_t height);
 /* The dispatch. Asynchronous on the context stream. */
 int  hrpt_render(HrptContext* ctx, const HrptFrameParams* params);
 int  hrpt_synchronize(HrptContext* ctx);
+/* Run all further work of the context on the caller's HIP stream (the counterpart of recording into the caller's
+ * command list, src/RenderGraph.cpp:329-349; also lets an RCCL all-gather follow the render without a host sync).
+ * useCallerStream != 0: hipStream is used as is (NULL = the legacy default stream); 0: back to the context's own
+ * stream. The previous stream is drained first. */
+int  hrpt_set_stream(HrptContext* ctx, void* hipStream, int useCallerStream);
 
 /* Device pointers of the two images (width*height float4, row-major) for zero-copy consumers
  * (the HDR post chain, RCCL all-gather). */

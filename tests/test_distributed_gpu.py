@@ -30,9 +30,11 @@ def test_device_tensor_view_and_rccl_allgather(luts):
         accum_ptr, out_ptr = ctx.device_images()
         full = device_tensor(accum_ptr, (72, 128, 4), dev)
 
+        # everything on torch's current stream (the default stream, handle 0): no host sync between render and collective
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
         def render_band(y0, y1):
             ctx.render(cb, accum_count=2, tile=(0, y0, 128, y1))
-            ctx.synchronize()
 
         # world 1 through the collective branch: band == whole image
         render_band(0, 72)
