@@ -363,6 +363,21 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     return HRPT_OK;
 }
 
+int hrpt_selftest_f16_decode(HrptContext* c, float* out65536)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!out65536) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_selftest_f16_decode: null out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, 65536 * sizeof(float)));
+    hipError_t e = launch_f16_table(d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out65536, d, 65536 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, HRPT_ERR_HIP, std::string("hrpt_selftest_f16_decode: ") + hipGetErrorString(e));
+    return HRPT_OK;
+}
+
 int hrpt_reset_stats(HrptContext* c)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

@@ -341,12 +341,19 @@ HRT_DEV f4 sample_texture(const SceneView& s, uint32_t texIndex, uint32_t sample
     f4 b = lerp4(texel8(t, x0, y1), texel8(t, x1, y1), tx);
     return lerp4(a, b, ty);
 }
+// binary16 -> binary32 is exact for every input, so the hardware conversion (v_cvt_f32_f16, fp16 denormals enabled --
+// the HIP default) gives the same bits as the integer decode of detmath.h (hrt_f16tof32) used on the host; checked for
+// all 65536 encodings by tests/test_parity_gpu.py::test_device_f16_decode_table.
+HRT_DEV float half_bits_to_float(uint32_t h)
+{
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
 HRT_DEV f4 lut_texel(const uint16_t* lut, size_t idx)
 {
     uint2 p = reinterpret_cast<const uint2*>(lut)[idx];   // 4 halfs = 8 B, one coalescable load
     f4 r;
-    r.x = hrt_f16tof32(p.x & 0xffffu); r.y = hrt_f16tof32(p.x >> 16);
-    r.z = hrt_f16tof32(p.y & 0xffffu); r.w = hrt_f16tof32(p.y >> 16);
+    r.x = half_bits_to_float(p.x & 0xffffu); r.y = half_bits_to_float(p.x >> 16);
+    r.z = half_bits_to_float(p.y & 0xffffu); r.w = half_bits_to_float(p.y >> 16);
     return r;
 }
 HRT_DEV int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }

@@ -25,6 +25,9 @@ struct TileRect { uint32_t x0, y0, x1, y1; };
 hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation,
                              float4* output, uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream);
 
+// Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).
+hipError_t launch_f16_table(float* out, hipStream_t stream);
+
 // Output[xy] = accum.rgb / accum.a (PathTracer.hlsl:339) over the whole image.
 hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream);
 

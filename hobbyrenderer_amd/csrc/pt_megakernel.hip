@@ -98,6 +98,17 @@ hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstan
     return hipGetLastError();
 }
 
+__global__ void pt_f16_table_kernel(float* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536u) out[i] = half_bits_to_float(i);
+}
+hipError_t launch_f16_table(float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_f16_table_kernel, dim3(256), dim3(256), 0, stream, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream)
 {
     if (pixelCount == 0) return hipSuccess;

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -50,6 +50,7 @@ lib.hrpt_write_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
+lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_halton.argtypes = [C.c_uint32, C.c_uint32]
 lib.hrpt_halton.restype = C.c_float
 lib.hrpt_precompute_atmosphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -152,6 +153,11 @@ class PathTracerContext:
         st = S.Stats()
         self._check(lib.hrpt_get_stats(self._h, C.byref(st)))
         return st
+
+    def selftest_f16_decode(self):
+        out = np.empty(65536, np.float32)
+        self._check(lib.hrpt_selftest_f16_decode(self._h, out.ctypes.data))
+        return out
 
     def reset_stats(self):
         self._check(lib.hrpt_reset_stats(self._h))

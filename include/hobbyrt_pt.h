@@ -271,6 +271,8 @@ int  hrpt_resolve_output(HrptContext* ctx);
 
 int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray counters are cumulative */
 int  hrpt_reset_stats(HrptContext* ctx);
+/* Device self-test: out65536[i] = the kernels' decode of the binary16 bit pattern i (RGBA16F LUT texels). */
+int  hrpt_selftest_f16_decode(HrptContext* ctx, float* out65536);
 
 /* Host-side helpers of PathTracerRenderer::Render, exported so that callers in other languages
  * produce the same constants: Halton (src/Utilities.cpp:67-79) and the CB fill (:58-75). */

@@ -204,3 +204,12 @@ def test_million_triangle_bvh(ctx, luts, flags):
     res = _run_both(ctx, sc, view, pos, 96, 54, 1, 6, flags)
     assert res[2].bvhTriangleCount > 1000000 and res[2].bvhMaxDepth < 32
     _assert_parity(*res)
+
+
+def test_device_f16_decode_table(ctx):
+    """The kernels decode RGBA16F LUT texels with the hardware conversion; it must equal the contract's integer decode
+    (detmath.h hrt_f16tof32 == numpy) for every one of the 65536 encodings, subnormals included."""
+    got = ctx.selftest_f16_decode()
+    ref = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    nan = np.isnan(ref)
+    assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]) and np.isnan(got[nan]).all()
