@@ -30,7 +30,8 @@ struct HrptContext {
     uint32_t bvhNodes = 0, bvhTris = 0;
     // images
     uint32_t width = 0, height = 0;
-    float4* dAccum = nullptr; float4* dOutput = nullptr;
+    float4* dAccum = nullptr; float4* dOutput = nullptr; float4* dDisplay = nullptr;
+    uint32_t* dHistogram = nullptr; float* dExposure = nullptr;   // persistent exposure buffer (HDRRenderer m_RG_ExposureBuffer)
     DeviceCounters* dCounters = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
@@ -131,6 +132,9 @@ void hrpt_destroy(HrptContext* c)
     wavefront_release(c->wf);
     if (c->dAccum) (void)hipFree(c->dAccum);
     if (c->dOutput) (void)hipFree(c->dOutput);
+    if (c->dDisplay) (void)hipFree(c->dDisplay);
+    if (c->dHistogram) (void)hipFree(c->dHistogram);
+    if (c->dExposure) (void)hipFree(c->dExposure);
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -228,6 +232,7 @@ int hrpt_resize(HrptContext* c, uint32_t width, uint32_t height)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->dAccum) { (void)hipFree(c->dAccum); c->dAccum = nullptr; }
     if (c->dOutput) { (void)hipFree(c->dOutput); c->dOutput = nullptr; }
+    if (c->dDisplay) { (void)hipFree(c->dDisplay); c->dDisplay = nullptr; }
     size_t bytes = (size_t)width * height * sizeof(float4);
     HIP_TRY(c, hipMalloc((void**)&c->dAccum, bytes));
     HIP_TRY(c, hipMalloc((void**)&c->dOutput, bytes));
@@ -360,6 +365,49 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     out->shadeKernelMs = c->wf.kernelMs[1]; out->shadeKernelLaunches = c->wf.kernelLaunches[1];
     out->shadowKernelMs = c->wf.kernelMs[2]; out->shadowKernelLaunches = c->wf.kernelLaunches[2];
     out->bvhNodeCount = c->bvhNodes; out->bvhTriangleCount = c->bvhTris; out->bvhMaxDepth = c->traits.bvhMaxDepth;
+    return HRPT_OK;
+}
+
+int hrpt_post_process(HrptContext* c, const HrptPostParams* p)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!p) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_post_process: null params");
+    if (!c->dOutput) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_post_process: hrpt_resize not called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->dExposure) {
+        HIP_TRY(c, hipMalloc((void**)&c->dExposure, 16));
+        HIP_TRY(c, hipMalloc((void**)&c->dHistogram, 256 * sizeof(uint32_t)));
+        const float one[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
+        HIP_TRY(c, hipMemcpy(c->dExposure, one, 16, hipMemcpyHostToDevice));
+    }
+    if (!c->dDisplay) HIP_TRY(c, hipMalloc((void**)&c->dDisplay, (size_t)c->width * c->height * sizeof(float4)));
+    HIP_TRY(c, launch_post_chain(c->dOutput, c->dDisplay, c->width * c->height, *p, c->dHistogram, c->dExposure, c->stream));
+    return HRPT_OK;
+}
+
+int hrpt_read_display(HrptContext* c, float* rgba, size_t bytes) { return read_image(c, c ? c->dDisplay : nullptr, rgba, bytes, "hrpt_read_display"); }
+
+int hrpt_get_exposure(HrptContext* c, float* exposure, uint32_t histogram256[256])
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!exposure || !c->dExposure) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_exposure: no post pass has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(exposure, c->dExposure, sizeof(float), hipMemcpyDeviceToHost));
+    if (histogram256) HIP_TRY(c, hipMemcpy(histogram256, c->dHistogram, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HRPT_OK;
+}
+
+int hrpt_set_exposure(HrptContext* c, float exposure)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->dExposure) {
+        HIP_TRY(c, hipMalloc((void**)&c->dExposure, 16));
+        HIP_TRY(c, hipMalloc((void**)&c->dHistogram, 256 * sizeof(uint32_t)));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->dExposure, &exposure, sizeof(float), hipMemcpyHostToDevice));
     return HRPT_OK;
 }
 

@@ -25,6 +25,10 @@ struct TileRect { uint32_t x0, y0, x1, y1; };
 hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation,
                              float4* output, uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream);
 
+// HDR post chain over `hdr` (W*H float4): histogram[256] + exposure[1] are context-owned device buffers.
+hipError_t launch_post_chain(const float4* hdr, float4* display, uint32_t pixelCount, const HrptPostParams& params, uint32_t* histogram,
+                             float* exposure, hipStream_t stream);
+
 // Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).
 hipError_t launch_f16_table(float* out, hipStream_t stream);
 

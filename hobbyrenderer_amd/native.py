@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -51,6 +51,10 @@ lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
+lib.hrpt_post_process.argtypes = [C.c_void_p, C.POINTER(S.PostParams)]
+lib.hrpt_read_display.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+lib.hrpt_get_exposure.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+lib.hrpt_set_exposure.argtypes = [C.c_void_p, C.c_float]
 lib.hrpt_halton.argtypes = [C.c_uint32, C.c_uint32]
 lib.hrpt_halton.restype = C.c_float
 lib.hrpt_precompute_atmosphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -153,6 +157,22 @@ class PathTracerContext:
         st = S.Stats()
         self._check(lib.hrpt_get_stats(self._h, C.byref(st)))
         return st
+
+    def post_process(self, params):
+        self._check(lib.hrpt_post_process(self._h, C.byref(params)))
+
+    def read_display(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib.hrpt_read_display(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def exposure(self):
+        e = C.c_float(); h = np.zeros(256, np.uint32)
+        self._check(lib.hrpt_get_exposure(self._h, C.byref(e), h.ctypes.data))
+        return e.value, h
+
+    def set_exposure(self, v):
+        self._check(lib.hrpt_set_exposure(self._h, v))
 
     def selftest_f16_decode(self):
         out = np.empty(65536, np.float32)

@@ -77,6 +77,12 @@ class DeviceDesc(C.Structure):
     _fields_ = [("deviceOrdinal", C.c_int32), ("abiVersion", C.c_uint32)]
 
 
+class PostParams(C.Structure):
+    _fields_ = [("autoExposure", C.c_uint32), ("manualExposure", C.c_float), ("deltaTimeSeconds", C.c_float), ("adaptationSpeed", C.c_float),
+                ("exposureValueMin", C.c_float), ("exposureValueMax", C.c_float), ("exposureCompensation", C.c_float),
+                ("hdrDisplay", C.c_uint32), ("maxDisplayNits", C.c_float)]
+
+
 class Stats(C.Structure):
     _fields_ = [("closestRays", C.c_uint64), ("shadowRays", C.c_uint64), ("paths", C.c_uint64),
                 ("lastRenderMs", C.c_float), ("traceKernelMs", C.c_float), ("traceKernelLaunches", C.c_uint32),

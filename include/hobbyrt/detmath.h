@@ -116,6 +116,50 @@ HRT_FN float hrt_exp(float x)
     return p * hrt_u2f((uint32_t)(n + 127) << 23);
 }
 
+/* log2(x) (cephes log2f polynomial): -inf at 0, NaN below; subnormal inputs are scaled first. Used by the HDR post
+ * chain (LuminanceHistogram.hlsl, ExposureAdaptation.hlsl, Tonemap.hlsl), not by the path tracer itself. */
+HRT_FN float hrt_log2(float x)
+{
+    if (x != x || x < 0.0f) return hrt_u2f(0x7fc00000u);
+    if (x == 0.0f) return hrt_u2f(0xff800000u);
+    uint32_t u = hrt_f2u(x);
+    if (u >= 0x7f800000u) return x;
+    int e = 0;
+    if (u < 0x00800000u) { x = x * 8388608.0f; u = hrt_f2u(x); e = -23; }
+    e += (int)(u >> 23) - 126;                                      /* x = m * 2^e, m in [0.5, 1) */
+    float m = hrt_u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else m = m - 1.0f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                    + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    y = y - 0.5f * z;                                               /* ln(1+m) - m */
+    const float LOG2EA = 0.44269504088896340736f;                   /* log2(e) - 1 */
+    float r = y * LOG2EA;
+    r = r + m * LOG2EA;
+    r = r + y;
+    r = r + m;
+    return r + (float)e;
+}
+/* exp2(x) (cephes exp2f polynomial); results below 2^-126 flush to zero. */
+HRT_FN float hrt_exp2(float x)
+{
+    if (x != x) return x;
+    if (x >= 128.0f) return hrt_u2f(0x7f800000u);
+    if (x < -126.0f) return 0.0f;
+    float px = __builtin_floorf(x);
+    int n = (int)px;
+    float r = x - px;
+    if (r > 0.5f) { n += 1; r = r - 1.0f; }
+    float p = (((((1.535336188319500e-4f * r + 1.339887440266574e-3f) * r + 9.618437357674640e-3f) * r + 5.550332471162809e-2f) * r
+                + 2.402264791363012e-1f) * r + 6.931472028550421e-1f) * r + 1.0f;
+    if (n > 127) { p = p * 2.0f; n -= 1; }
+    if (n < -126) return 0.0f;
+    return p * hrt_u2f((uint32_t)(n + 127) << 23);
+}
+/* HLSL pow(x, y) = exp2(y * log2(x)) (x > 0; pow(0, y>0) = 0). */
+HRT_FN float hrt_pow(float x, float y) { return hrt_exp2(y * hrt_log2(x)); }
+
 /* HLSL f16tof32 of the low 16 bits (MeshCommon.hlsli:20; RGBA16F LUT texels). Exact. */
 HRT_FN float hrt_f16tof32(uint32_t h)
 {

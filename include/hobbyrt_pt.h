@@ -269,6 +269,27 @@ int  hrpt_write_accumulation(HrptContext* ctx, const float* rgba, size_t bytes);
 /* Output = accum.rgb / accum.a for every pixel (PathTracer.hlsl:339), e.g. after an all-gather of accumulation tiles. */
 int  hrpt_resolve_output(HrptContext* ctx);
 
+/* ---- HDR post chain: the consumer of the pass -------------------------------------------------
+ * HDRRenderer::Render (src/HDRRenderer.cpp:88-224) over Output (u0 = g_RG_HDRColor in path-tracer mode):
+ * luminance histogram (src/shaders/LuminanceHistogram.hlsl), exposure adaptation (ExposureAdaptation.hlsl) or manual
+ * exposure (Camera::m_Exposure, src/Camera.cpp:107-108), then Tonemap_PSMain (PBR-Neutral + sRGB OETF) or
+ * TonemapHDR_PSMain (scRGB roll-off) of src/shaders/Tonemap.hlsl into a W x H float4 display image. */
+typedef struct HrptPostParams {
+    uint32_t autoExposure;          /* Renderer::m_EnableAutoExposure (src/Renderer.h:303) */
+    float    manualExposure;        /* Camera::m_Exposure = 1 / (2^EV * 1.2); used when autoExposure == 0 */
+    float    deltaTimeSeconds;      /* m_FrameTime / 1000 */
+    float    adaptationSpeed;       /* Renderer::m_AdaptationSpeed, default 5 */
+    float    exposureValueMin;      /* Camera::m_ExposureValueMin, default -7 */
+    float    exposureValueMax;      /* Camera::m_ExposureValueMax, default 23 */
+    float    exposureCompensation;  /* Camera::m_ExposureCompensation */
+    uint32_t hdrDisplay;            /* GraphicRHI::m_bIsHDR: 0 = Tonemap_PSMain, 1 = TonemapHDR_PSMain */
+    float    maxDisplayNits;        /* GraphicRHI::m_MaxDisplayNits */
+} HrptPostParams;
+int  hrpt_post_process(HrptContext* ctx, const HrptPostParams* params);
+int  hrpt_read_display(HrptContext* ctx, float* rgba, size_t bytes);           /* W*H*16 bytes */
+int  hrpt_get_exposure(HrptContext* ctx, float* exposure, uint32_t histogram256[256]);   /* histogram may be NULL */
+int  hrpt_set_exposure(HrptContext* ctx, float exposure);                      /* the persistent exposure buffer, initially 1 */
+
 int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray counters are cumulative */
 int  hrpt_reset_stats(HrptContext* ctx);
 /* Device self-test: out65536[i] = the kernels' decode of the binary16 bit pattern i (RGBA16F LUT texels). */

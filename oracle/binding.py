@@ -70,6 +70,13 @@ def lib():
         L.or_sky_radiance.restype = None
         L.or_sun_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.or_sun_radiance.restype = None
+        L.or_post_process.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        L.or_post_process.restype = None
+        for n in ("or_log2", "or_exp2"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [C.c_float]
+        L.or_pow.restype = C.c_float
+        L.or_pow.argtypes = [C.c_float, C.c_float]
         _lib = L
     return _lib
 
@@ -136,3 +143,14 @@ class Oracle:
         a, b = (np.ascontiguousarray(x, np.float32) for x in (world_pos, sun_dir))
         lib().or_sun_radiance(self._h, a.ctypes.data, b.ctypes.data, sun_intensity, out.ctypes.data)
         return out
+
+
+def post_process(hdr, params, exposure):
+    """HDR post chain of the oracle. hdr: (H, W, 4) float32; params: structs.PostParams; returns (display, exposure, histogram)."""
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    h, w = hdr.shape[:2]
+    disp = np.empty_like(hdr)
+    hist = np.zeros(256, np.uint32)
+    e = C.c_float(exposure)
+    lib().or_post_process(hdr.ctypes.data, w, h, C.addressof(params), C.byref(e), hist.ctypes.data, disp.ctypes.data)
+    return disp, e.value, hist

@@ -1344,3 +1344,85 @@ int or_trace_closest(OrContext* c, const float o[3], const float d[3], float tmi
     *inst = h.inst; *prim = h.prim; bary[0] = h.u; bary[1] = h.v; *t = h.t;
     return 1;
 }
+
+/* ------------------------------------------------------------------ HDR post chain */
+float or_log2(float x) { return hrt_log2(x); }
+float or_exp2(float x) { return hrt_exp2(x); }
+float or_pow(float x, float y) { return hrt_pow(x, y); }
+
+/* PBRNeutralToneMapping, Tonemap.hlsl:13-33 */
+static v3 pbr_neutral(v3 c)
+{
+    const float startCompression = 0.8f - 0.04f, desaturation = 0.15f;
+    float x = hrt_min(c.x, hrt_min(c.y, c.z));
+    float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+    c = V3(c.x - offset, c.y - offset, c.z - offset);
+    float peak = hrt_max(c.x, hrt_max(c.y, c.z));
+    if (peak < startCompression) return c;
+    const float d = 1.0f - startCompression;
+    float newPeak = 1.0f - d * d / (peak + d - startCompression);
+    float k = newPeak / peak;
+    c = scale3(c, k);
+    float g = 1.0f - 1.0f / (desaturation * (peak - newPeak) + 1.0f);
+    return V3(lerp1(c.x, newPeak * 1.0f, g), lerp1(c.y, newPeak * 1.0f, g), lerp1(c.z, newPeak * 1.0f, g));
+}
+/* sRGB_OETF, Tonemap.hlsl:35-42 */
+static float srgb_oetf(float x)
+{
+    float v = (x <= 0.0031308f) ? x * 12.92f : 1.055f * hrt_pow(x, 1.0f / 2.4f) - 0.055f;
+    return hrt_saturate(v);
+}
+/* HDRDisplayTonemap, Tonemap.hlsl:72-92 */
+static v3 hdr_display_tonemap(v3 x, float maxNits)
+{
+    float maxSCRGB = maxNits / 80.0f;
+    float lum = hrt_max(x.x, hrt_max(x.y, x.z));
+    if (lum <= 1.0f) return x;
+    float headroom = maxSCRGB - 1.0f, excess = lum - 1.0f;
+    float compressed = excess * headroom / (excess + headroom);
+    float newLum = 1.0f + compressed;
+    float k = newLum / lum;
+    return V3(hrt_min(x.x * k, maxSCRGB), hrt_min(x.y * k, maxSCRGB), hrt_min(x.z * k, maxSCRGB));
+}
+void or_post_process(const float* hdr, uint32_t W, uint32_t H, const HrptPostParams* p, float* exposure, uint32_t histogram[256], float* display)
+{
+    const float kMinLog = -10.0f, kMaxLog = 20.0f;   /* src/HDRRenderer.cpp:12-13 */
+    uint32_t hist[256]; memset(hist, 0, sizeof hist);
+    if (p->autoExposure) {
+        /* LuminanceHistogram_CSMain */
+        for (size_t i = 0; i < (size_t)W * H; i++) {
+            v3 c = V3(hdr[i * 4], hdr[i * 4 + 1], hdr[i * 4 + 2]);
+            float lum = dot3(c, V3(0.2126f, 0.7152f, 0.0722f));
+            uint32_t bin = 0;
+            if (!(lum < 0.0001f)) {
+                float range = kMaxLog - kMinLog;
+                float logLum = hrt_clamp((hrt_log2(lum) - kMinLog) / range, 0.0f, 1.0f);
+                bin = (uint32_t)(logLum * 254.0f + 1.0f);
+            }
+            hist[bin]++;
+        }
+        /* ExposureAdaptation_CSMain: the 256-wide shared-memory tree, same order */
+        float w[256]; float range = kMaxLog - kMinLog;
+        for (uint32_t t = 0; t < 256; t++) {
+            float logLum = t == 0 ? kMinLog : (kMinLog + ((float)(t - 1) / 254.0f) * range);
+            w[t] = (float)hist[t] * logLum;
+        }
+        for (uint32_t i = 128; i > 0; i >>= 1) for (uint32_t t = 0; t < i; t++) w[t] += w[t + i];
+        float avgLogLum = w[0] / hrt_max((float)(W * H), 1.0f);
+        float avgLum = hrt_exp2(avgLogLum);
+        float EV100 = hrt_log2(avgLum * 100.0f / 12.5f);
+        EV100 = hrt_clamp(EV100, p->exposureValueMin, p->exposureValueMax);
+        EV100 -= p->exposureCompensation;
+        float target = 1.0f / (hrt_pow(2.0f, EV100) * 1.2f);
+        float cur = *exposure;
+        *exposure = cur + (target - cur) * (1.0f - hrt_exp(-p->deltaTimeSeconds * p->adaptationSpeed));
+    } else *exposure = p->manualExposure;   /* writeBuffer(exposureBuffer, &m_Camera.m_Exposure), src/HDRRenderer.cpp:163 */
+    if (histogram) memcpy(histogram, hist, sizeof hist);
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        v3 c = scale3(V3(hdr[i * 4], hdr[i * 4 + 1], hdr[i * 4 + 2]), *exposure);
+        v3 o;
+        if (p->hdrDisplay) o = hdr_display_tonemap(c, p->maxDisplayNits);
+        else { v3 t = pbr_neutral(c); o = V3(srgb_oetf(t.x), srgb_oetf(t.y), srgb_oetf(t.z)); }
+        display[i * 4] = o.x; display[i * 4 + 1] = o.y; display[i * 4 + 2] = o.z; display[i * 4 + 3] = 1.0f;
+    }
+}

@@ -59,6 +59,12 @@ void  or_fill_constants(HrptPathTracerConstants* cb, const HrptPlanarViewConstan
                         uint32_t frameIndex, uint32_t maxBounces, const float sunDirection[3],
                         float sunAngularSizeDeg);
 
+/* HDR post chain: LuminanceHistogram.hlsl + ExposureAdaptation.hlsl (or manual exposure) +
+ * Tonemap.hlsl over a W x H float4 HDR image. *exposure is the persistent exposure buffer (in/out). */
+void  or_post_process(const float* hdr, uint32_t width, uint32_t height, const HrptPostParams* params, float* exposure,
+                      uint32_t histogram[256], float* display);
+float or_log2(float x); float or_exp2(float x); float or_pow(float x, float y);
+
 /* Scalar probes for known-answer tests. */
 uint32_t or_pcg_hash(uint32_t v);
 uint32_t or_init_rng(uint32_t px, uint32_t py, uint32_t accumIndex);

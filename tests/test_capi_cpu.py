@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_every_declared_symbol_is_exported():
     hdr = open(os.path.join(ROOT, "include", "hobbyrt_pt.h")).read()
-    declared = set(re.findall(r"\b(hrpt_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hrpt_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for name in declared:
         assert getattr(native.lib, name) is not None
