@@ -44,11 +44,21 @@ __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerC
                 SurfaceCarry carry;
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 f3 neeThroughput;
-                SurfaceOutcome oc = shade_surface_a<true, true, false>(s, cb, ps, hit, carry, [&](uint32_t, f3 worldPos, f3 L, float maxDist, f3 dif, f3 spec) {
+                const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+                const float sunIntensity = s.lights[0].m_Intensity;                  // g_Lights[0], PathTracer.hlsl:137 (quirk kept)
+                SurfaceOutcome oc = shade_surface_a<true, true, false>(s, cb, ps, hit, carry, [&](uint32_t li, float ux, float uy) {
+                    HrptGPULight l = load_light(s, li);
+                    f3 L; float maxDist;
+                    if (!nee_direction<false>(l, carry.N, carry.worldPos, sunDir, cb.m_CosSunAngularRadius, ux, uy, L, maxDist)) return;
                     ++nShadow;
-                    float shadow = shadow_query(s, bvh, worldPos, L, maxDist, stack);
-                    totalDiffuse = totalDiffuse + dif * shadow;
-                    totalSpecular = totalSpecular + spec * shadow;
+                    float shadow = shadow_query(s, bvh, carry.worldPos, L, maxDist, stack);
+                    if (shadow != 0.0f) {                                              // an occluded sample contributes +0
+                        f3 dif, spec;
+                        nee_contribution<false>(s, l, nee_lighting(carry.N, carry.V, carry.baseColor, carry.roughness, carry.metallic, carry.ior),
+                                                carry.worldPos, sunDir, sunIntensity, L, dif, spec);
+                        totalDiffuse = totalDiffuse + dif * shadow;
+                        totalSpecular = totalSpecular + spec * shadow;
+                    }
                 });
                 if (oc == SURFACE_TRANSMITTED) continue;
                 neeThroughput = ps.throughput;

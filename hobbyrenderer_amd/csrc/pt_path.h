@@ -23,7 +23,7 @@ struct PathState {
 
 // what shade_surface_a needs to keep for shade_surface_b
 struct SurfaceCarry {
-    f3 N, V, worldPos, baseColor, F0; float Fr, roughness, metallic;
+    f3 N, V, worldPos, baseColor, F0; float Fr, roughness, metallic, ior;
 };
 
 HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_t px, uint32_t py)
@@ -128,67 +128,105 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
     return hrt_saturate(transmission);
 }
 
-// One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908): early-outs, the jittered sample
-// (2 RNG draws when reached), per-sample byproducts and the unshadowed EvaluateDirectLight terms.
-// Returns false when the light contributes nothing and casts no shadow ray.
+// One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908) in three stages, so that a schedule may run the
+// expensive parts where lanes are dense and skip them for occluded samples (a shadow factor of 0 contributes +0):
+//   nee_draw          early-outs that precede the RNG draws (:723, :758-764, :815-833) + the two draws (:730, :776, :846)
+//   nee_direction     jittered direction / distance from the draws; false when dot(N, L_s) <= 0 (no shadow ray, :731/:786/:856)
+//   nee_contribution  radiance (sun: atmosphere LUT; point/spot: attenuation) + per-sample byproducts + EvaluateDirectLight
+//                     without the shadow factor
 // DIRONLY: the scene's light list is known to hold directional lights only (point/spot code compiled out).
 template <bool DIRONLY>
-HRT_DEV bool nee_sample(const SceneView& s, const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunDirection, float sunIntensity, float cosSun,
-                        uint32_t& rng, f3& L, float& maxDist, f3& diffuse, f3& specular)
+HRT_DEV bool nee_draw(const HrptGPULight& l, f3 N, f3 worldPos, f3 sunDirection, uint32_t& rng, float& ux, float& uy)
 {
-    f3 radiance;
     if (DIRONLY || l.m_Type == HRPT_LIGHT_DIRECTIONAL) {                        // :716-745
-        if (dot(in.N, sunDirection) <= 0.0f) return false;
-        // inputs.sunRadiance (PathTracer.hlsl:137) is a pure function of the hit position and is only read past this
-        // early-out, so it is evaluated here (one transmittance-LUT fetch) instead of for every hit.
-        radiance = atm::sun_radiance(s, atm::atmosphere_pos(worldPos), sunDirection, sunIntensity);
-        float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
-        L = sample_cone(sunDirection, cosSun, ux, uy);
-        maxDist = 1e10f;
+        if (dot(N, sunDirection) <= 0.0f) return false;
     } else if (!DIRONLY && (l.m_Type == HRPT_LIGHT_POINT || l.m_Type == HRPT_LIGHT_SPOT)) {   // :752-804, :809-874
         if (l.m_Intensity <= 0.0f) return false;
-        f3 lp = mk3(l.m_Position);
-        f3 toLight = lp - worldPos;
+        f3 toLight = mk3(l.m_Position) - worldPos;
         float distSq = dot(toLight, toLight);
         if (l.m_Range > 0.0f && distSq > l.m_Range * l.m_Range) return false;
-        float dist = hrt_sqrt(distSq);
-        float spotAtt = 1.0f;
         if (l.m_Type == HRPT_LIGHT_SPOT) {
+            float dist = hrt_sqrt(distSq);
             f3 Lc = toLight / dist;
-            if (dot(in.N, Lc) <= 0.0f) return false;
+            if (dot(N, Lc) <= 0.0f) return false;
             f3 lightDir = normalize(mk3(l.m_Direction));
             float cosTheta = dot(-Lc, lightDir);
-            float cosOuter = hrt_cos(l.m_SpotOuterConeAngle);
-            if (cosTheta < cosOuter) return false;
-            float cosInner = hrt_cos(l.m_SpotInnerConeAngle);
-            spotAtt = hrt_saturate((cosTheta - cosOuter) / (cosInner - cosOuter));
+            if (cosTheta < hrt_cos(l.m_SpotOuterConeAngle)) return false;
         }
-        float att = distance_attenuation(l, distSq, dist);
-        f3 col = mk3(l.m_Color);
-        radiance = (l.m_Type == HRPT_LIGHT_SPOT) ? ((col * l.m_Intensity) * spotAtt) * att : (col * l.m_Intensity) * att;
-        float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);
+    } else return false;
+    ux = hrt_rng_next(&rng); uy = hrt_rng_next(&rng);
+    return true;
+}
+
+template <bool DIRONLY>
+HRT_DEV bool nee_direction(const HrptGPULight& l, f3 N, f3 worldPos, f3 sunDirection, float cosSun, float ux, float uy, f3& L, float& maxDist)
+{
+    if (DIRONLY || l.m_Type == HRPT_LIGHT_DIRECTIONAL) {
+        L = sample_cone(sunDirection, cosSun, ux, uy);
+        maxDist = 1e10f;
+    } else {
         float cosT = 1.0f - 2.0f * ux;
         float sinT = hrt_sqrt(hrt_max(0.0f, 1.0f - cosT * cosT));
         float phi = 2.0f * HRT_PI * uy;
         float sp, cp; hrt_sincos(phi, &sp, &cp);
         f3 sphereDir = mk3(sinT * cp, cosT, sinT * sp);
-        f3 samplePos = lp + sphereDir * l.m_Radius;
+        f3 samplePos = mk3(l.m_Position) + sphereDir * l.m_Radius;
         f3 toSample = samplePos - worldPos;
         float sampleDist = length(toSample);
         L = toSample / sampleDist;
         maxDist = sampleDist;
-    } else return false;
-    if (dot(in.N, L) <= 0.0f) return false;
+    }
+    return !(dot(N, L) <= 0.0f);
+}
+
+template <bool DIRONLY>
+HRT_DEV void nee_contribution(const SceneView& s, const HrptGPULight& l, Lighting in, f3 worldPos, f3 sunDirection, float sunIntensity, f3 L,
+                              f3& diffuse, f3& specular)
+{
+    f3 radiance;
+    if (DIRONLY || l.m_Type == HRPT_LIGHT_DIRECTIONAL) {
+        // inputs.sunRadiance (PathTracer.hlsl:137): a pure function of the hit position, read only by directional lights
+        radiance = atm::sun_radiance(s, atm::atmosphere_pos(worldPos), sunDirection, sunIntensity);
+    } else {
+        f3 toLight = mk3(l.m_Position) - worldPos;
+        float distSq = dot(toLight, toLight);
+        float dist = hrt_sqrt(distSq);
+        float att = distance_attenuation(l, distSq, dist);
+        f3 col = mk3(l.m_Color);
+        if (l.m_Type == HRPT_LIGHT_SPOT) {
+            f3 Lc = toLight / dist;
+            f3 lightDir = normalize(mk3(l.m_Direction));
+            float cosTheta = dot(-Lc, lightDir);
+            float cosOuter = hrt_cos(l.m_SpotOuterConeAngle), cosInner = hrt_cos(l.m_SpotInnerConeAngle);
+            float spotAtt = hrt_saturate((cosTheta - cosOuter) / (cosInner - cosOuter));
+            radiance = ((col * l.m_Intensity) * spotAtt) * att;
+        } else radiance = (col * l.m_Intensity) * att;
+    }
     in.L = L;
     prepare_byproducts(in);
     evaluate_direct_unshadowed(in, radiance, diffuse, specular);
-    return true;
+}
+
+// The surface terms a deferred NEE evaluation needs (what LightingInputs carries into AccumulateDirectLighting).
+HRT_DEV Lighting nee_lighting(f3 N, f3 V, f3 baseColor, float roughness, float metallic, float ior)
+{
+    Lighting in;
+    in.N = N; in.V = V; in.L = mk3(0.0f, 0.0f, 0.0f); in.baseColor = baseColor; in.roughness = roughness; in.metallic = metallic; in.ior = ior;
+    return in;
+}
+
+HRT_DEV HrptGPULight load_light(const SceneView& s, uint32_t i)
+{
+    if (i < s.lightCount) return s.lights[i];
+    HrptGPULight l = HrptGPULight(); l.m_Type = 0;   // out-of-range structured-buffer read returns zeros on D3D12
+    return l;
 }
 
 enum SurfaceOutcome { SURFACE_TRANSMITTED = 0, SURFACE_SCATTER = 1 };
 
-// PathTracer.hlsl:92-261 up to the light loop. EMIT(lightOrdinal, worldPos, L, maxDist, diffuse, specular) receives
-// each light sample; the caller owes  radiance += neeThroughput * (sum(diffuse_i*shadow_i) + (bounce==0 ? sum(specular_i*shadow_i) : 0)).
+// PathTracer.hlsl:92-261 up to the light loop. EMIT(lightIndex, ux, uy) receives the two random numbers of every light
+// that passed nee_draw (carry is filled before the first call); the caller runs nee_direction, the shadow query and
+// nee_contribution, and owes  radiance += throughput * (sum(diffuse_i*shadow_i) + (bounce==0 ? sum(specular_i*shadow_i) : 0)).
 // Compile-time scene traits (all-true / DIRONLY=false is the general form and always correct):
 //   TEX     some material samples a texture          (false: every m_TextureFlags is 0 -> sampling code compiled out)
 //   TRANS   some material is transmissive or BLEND   (false: the transmission branch :149-255 is compiled out)
@@ -217,7 +255,6 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     if (dot(N, V) < 0.0f) N = -N;
 
     f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
-    float sunIntensity = s.lights[0].m_Intensity;                                 // g_Lights[0] :137 (reference quirk kept)
 
     Lighting in;
     in.N = N; in.V = V; in.L = mk3(0.0f, 0.0f, 0.0f); in.baseColor = pbr.baseColor;
@@ -269,15 +306,13 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
 
     ps.radiance = ps.radiance + ps.throughput * pbr.emissive;                     // :258
 
-    for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
-        HrptGPULight l;
-        if (i < s.lightCount) l = s.lights[i]; else { l = HrptGPULight(); l.m_Type = 0; }   // OOB structured read = zeros
-        f3 L, dif, spec; float maxDist;
-        if (nee_sample<DIRONLY>(s, l, in, attr.worldPos, sunDir, sunIntensity, cb.m_CosSunAngularRadius, ps.rng, L, maxDist, dif, spec))
-            emit(i, attr.worldPos, L, maxDist, dif, spec);
-    }
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;
-    carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic;
+    carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic; carry.ior = mat.m_IOR;
+    for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
+        HrptGPULight l = load_light(s, i);
+        float ux, uy;
+        if (nee_draw<DIRONLY>(l, N, attr.worldPos, sunDir, ps.rng, ux, uy)) emit(i, ux, uy);
+    }
     return SURFACE_SCATTER;
 }
 

@@ -8,7 +8,10 @@
 // Data layout in HBM (one pool, SoA of float4, all streams coalesced 16 B/lane):
 //   path queues A/B (ping-pong per bounce): rayO{o.xyz,tmin} rayD{d.xyz,rng} thr{T.xyz,sample} [med0{sigmaA,ior} med1{sigmaS,inVolume}]
 //   hit records of the current queue:       hit{t,u,v,triangle}  (triangle = leaf-order index, 0xFFFFFFFF = miss)
-//   shadow queue:                           sh0{origin,sample} sh1{T,count} + per light sample shL{L,maxDist} shD{diffuse} shS{specular}
+//   NEE / shadow queue (dense):             sh0{origin,sample} sh1{N,roughness} sh2{V,metallic} sh3{baseColor,ior} sh4{T,count}
+//                                           + per light sample shL{ux,uy,light}: direction, visibility and the BRDF x radiance
+//                                           evaluation are done by wf_shadow, where every lane has NEE work and occluded
+//                                           samples skip the evaluation
 //   sampleRadiance[sample] (rgb): one slot per (pixel, accumulation index); emissive / NEE / sky are added in path order,
 //                                 wf_resolve then folds the indices in order exactly like progressive accumulation (:332-339).
 // Queues are SEGMENTED: a segment is 1024 consecutive samples owned by ONE wave at a time. The owning wave
@@ -38,7 +41,7 @@ struct WfBuffers {
     float4 *rayO[2], *rayD[2], *thr[2], *med0[2], *med1[2];
     uint32_t* pathCnt[2];
     float4* hit;
-    float4 *sh0, *sh1, *shL, *shD, *shS;
+    float4 *sh0, *sh1, *sh2, *sh3, *sh4, *shL;
     uint32_t* shadowCnt;
     float4* radiance;
 };
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 
 // ------------------------------------------------------------------ shade (+ compaction, + NEE sample emission)
 template <int MAXL>
-struct NeeBuf { f3 L[MAXL]; float maxDist[MAXL]; f3 dif[MAXL], spec[MAXL]; };
+struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 
 // SIMPLE: scene traits proven at upload -- no textures, no transmissive / BLEND material, directional lights only --
 // compile the corresponding branches out (the general variant is always correct).
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
             uint32_t i = base + lane;
             bool valid = i < cnt, alive = false;
             uint32_t nNee = 0, smp = 0;
-            PathState ps; f3 worldPos = mk3(0.0f, 0.0f, 0.0f), neeT = mk3(0.0f, 0.0f, 0.0f);
-            NeeBuf<MAXL> nee;
+            PathState ps; f3 neeT = mk3(0.0f, 0.0f, 0.0f);
+            NeeBuf<MAXL> nee; SurfaceCarry carry;
             if (valid) {
                 uint32_t slot = segBase + i;
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
@@ -319,14 +322,9 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                 bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
                 if (tri != 0xFFFFFFFFu) {
                     Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
-                    SurfaceCarry carry;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
-                    SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t, f3 wp, f3 L, float maxDist, f3 dif, f3 spec) {
-                        if (nNee < (uint32_t)MAXL) {
-                            worldPos = wp;
-                            nee.L[nNee] = L; nee.maxDist[nNee] = maxDist; nee.dif[nNee] = dif; nee.spec[nNee] = spec;
-                            ++nNee;
-                        }
+                    SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t li, float ux, float uy) {
+                        if (nNee < (uint32_t)MAXL) { nee.ux[nNee] = ux; nee.uy[nNee] = uy; nee.light[nNee] = li; ++nNee; }
                     });
                     if (oc == SURFACE_TRANSMITTED) alive = true;
                     else {
@@ -365,17 +363,14 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
             unsigned long long ms = __ballot(nNee > 0);
             if (nNee > 0) {
                 uint32_t e = segBase + shCount + prefix_rank(ms);
-                a.b.sh0[e] = make_float4(worldPos.x, worldPos.y, worldPos.z, __uint_as_float(smp));
-                a.b.sh1[e] = make_float4(neeT.x, neeT.y, neeT.z, __uint_as_float(nNee));
+                a.b.sh0[e] = make_float4(carry.worldPos.x, carry.worldPos.y, carry.worldPos.z, __uint_as_float(smp));
+                a.b.sh1[e] = make_float4(carry.N.x, carry.N.y, carry.N.z, carry.roughness);
+                a.b.sh2[e] = make_float4(carry.V.x, carry.V.y, carry.V.z, carry.metallic);
+                a.b.sh3[e] = make_float4(carry.baseColor.x, carry.baseColor.y, carry.baseColor.z, carry.ior);
+                a.b.sh4[e] = make_float4(neeT.x, neeT.y, neeT.z, __uint_as_float(nNee));
 #pragma unroll
-                for (int j = 0; j < MAXL; ++j) {
-                    if ((uint32_t)j < nNee) {
-                        size_t q = (size_t)e * a.maxLights + j;
-                        a.b.shL[q] = make_float4(nee.L[j].x, nee.L[j].y, nee.L[j].z, nee.maxDist[j]);
-                        a.b.shD[q] = make_float4(nee.dif[j].x, nee.dif[j].y, nee.dif[j].z, 0.0f);
-                        if (bounce == 0) a.b.shS[q] = make_float4(nee.spec[j].x, nee.spec[j].y, nee.spec[j].z, 0.0f);
-                    }
-                }
+                for (int j = 0; j < MAXL; ++j)
+                    if ((uint32_t)j < nNee) a.b.shL[(size_t)e * a.maxLights + j] = make_float4(nee.ux[j], nee.uy[j], __uint_as_float(nee.light[j]), 0.0f);
             }
             shCount += (uint32_t)__popcll(ms);
         }
@@ -384,13 +379,16 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
 }
 
 // ------------------------------------------------------------------ shadow (NEE visibility + accumulation)
-template <bool LDS_BVH, int DEPTH>
-__global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
+template <bool LDS_BVH, int DEPTH, bool DIRONLY>
+__global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStack<DEPTH> stack; LdsBvh lbvh;
     setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
     GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+    const SceneView& s = a.scene;
+    const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+    const float sunIntensity = s.lights[0].m_Intensity;      // g_Lights[0], PathTracer.hlsl:137 (reference quirk kept)
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
@@ -401,21 +399,26 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
             uint32_t i = base + lane;
             if (i < cnt) {
                 uint32_t e = segBase + i;
-                float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e];
-                f3 origin = mk3(h0.x, h0.y, h0.z), T = mk3(h1.x, h1.y, h1.z);
-                uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h1.w);
+                float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], h4 = a.b.sh4[e];
+                f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), T = mk3(h4.x, h4.y, h4.z);
+                uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 for (uint32_t j = 0; j < n; ++j) {
-                    size_t q = (size_t)e * a.maxLights + j;
-                    float4 l = a.b.shL[q];
+                    float4 ls = a.b.shL[(size_t)e * a.maxLights + j];
+                    HrptGPULight l = load_light(s, __float_as_uint(ls.z));
+                    f3 L; float maxDist;
+                    if (!nee_direction<DIRONLY>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ls.x, ls.y, L, maxDist)) continue;
                     float shadow;
-                    if (LDS_BVH) shadow = shadow_query(a.scene, lbvh, origin, mk3(l.x, l.y, l.z), l.w, stack);
-                    else shadow = shadow_query(a.scene, gbvh, origin, mk3(l.x, l.y, l.z), l.w, stack);
+                    if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
+                    else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
                     ++nRays;
-                    if (shadow != 0.0f) {   // (x*0) contributes +0: skipped, sums are unchanged
-                        float4 dd = a.b.shD[q];
-                        totalDiffuse = totalDiffuse + mk3(dd.x, dd.y, dd.z) * shadow;
-                        if (bounce == 0) { float4 ss = a.b.shS[q]; totalSpecular = totalSpecular + mk3(ss.x, ss.y, ss.z) * shadow; }
+                    if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped
+                        float4 h2 = a.b.sh2[e], h3 = a.b.sh3[e];
+                        f3 dif, spec;
+                        nee_contribution<DIRONLY>(s, l, nee_lighting(N, mk3(h2.x, h2.y, h2.z), mk3(h3.x, h3.y, h3.z), h1.w, h2.w, h3.w), origin, sunDir,
+                                                  sunIntensity, L, dif, spec);
+                        totalDiffuse = totalDiffuse + dif * shadow;
+                        if (bounce == 0) totalSpecular = totalSpecular + spec * shadow;
                     }
                 }
                 f3 dsum = totalDiffuse + (bounce == 0 ? totalSpecular : mk3(0.0f, 0.0f, 0.0f));
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, int bounce)
             }
         }
     }
+    (void)lane;
     block_count_add(&a.counters->closestRays, 1, nRays);
 }
 
@@ -460,17 +464,21 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 struct Variant { bool lds; int depth; };
 
 template <bool L, int D> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D>), g, dim3(kBlock), sh, st, a, parity); }
-template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, int bounce) { hipLaunchKernelGGL((wf_shadow<L, D>), g, dim3(kBlock), sh, st, a, bounce); }
+template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly)
+{
+    if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<L, D, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+}
 
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
 {
     if (v.lds) { if (v.depth <= 8) launch_extend_t<true, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<true, 16>(g, sh, st, a, parity); else launch_extend_t<true, 32>(g, sh, st, a, parity); }
     else { if (v.depth <= 8) launch_extend_t<false, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<false, 16>(g, sh, st, a, parity); else launch_extend_t<false, 32>(g, sh, st, a, parity); }
 }
-void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, int bounce)
+void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly)
 {
-    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, bounce); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, bounce); else launch_shadow_t<true, 32>(g, sh, st, a, bounce); }
-    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, bounce); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, bounce); else launch_shadow_t<false, 32>(g, sh, st, a, bounce); }
+    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, cb, bounce, dirOnly); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, cb, bounce, dirOnly); else launch_shadow_t<true, 32>(g, sh, st, a, cb, bounce, dirOnly); }
+    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, cb, bounce, dirOnly); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, cb, bounce, dirOnly); else launch_shadow_t<false, 32>(g, sh, st, a, cb, bounce, dirOnly); }
 }
 
 } // namespace
@@ -549,8 +557,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         oCnt[p] = carve((size_t)segs * 4);
     }
     size_t oHit = carve(capacity * 16);
-    size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16);
-    size_t oShL = carve(capacity * 16 * maxLights), oShD = carve(capacity * 16 * maxLights), oShS = carve(capacity * 16 * maxLights);
+    size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16), oSh2 = carve(capacity * 16), oSh3 = carve(capacity * 16), oSh4 = carve(capacity * 16);
+    size_t oShL = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
     if (off > st.poolBytes) {
         if (st.pool) { (void)hipStreamSynchronize(stream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
@@ -566,8 +574,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         a.b.med0[p] = (float4*)(base + oMed0[p]); a.b.med1[p] = (float4*)(base + oMed1[p]); a.b.pathCnt[p] = (uint32_t*)(base + oCnt[p]);
     }
     a.b.hit = (float4*)(base + oHit);
-    a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1);
-    a.b.shL = (float4*)(base + oShL); a.b.shD = (float4*)(base + oShD); a.b.shS = (float4*)(base + oShS);
+    a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1); a.b.sh2 = (float4*)(base + oSh2); a.b.sh3 = (float4*)(base + oSh3);
+    a.b.sh4 = (float4*)(base + oSh4); a.b.shL = (float4*)(base + oShL);
     a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
     a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
     a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
@@ -621,7 +629,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
-            launch_shadow(v, dim3(grid), traceLds, stream, a, bounce);
+            launch_shadow(v, dim3(grid), traceLds, stream, a, cb, bounce, traits.directionalLightsOnly);
             if (timed) timing_mark(st, stream, 2, false);
         }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;
