@@ -217,6 +217,7 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
         if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;
         if (m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND && !(m.m_TransmissionFactor > 0.0f)) c->traits.hasStochasticAlpha = true;
         if (m.m_TextureFlags != 0) c->traits.hasTextures = true;
+        if (m.m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) c->traits.hasNonOpaque = true;
         if (m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) c->traits.hasTransmissiveOrBlend = true;
     }
     for (uint32_t i = 0; i < s->lightCount; ++i) if (s->lights[i].m_Type != HRPT_LIGHT_DIRECTIONAL) c->traits.directionalLightsOnly = false;

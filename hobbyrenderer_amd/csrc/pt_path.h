@@ -77,55 +77,156 @@ HRT_DEV bool trace_standard(const SceneView& s, const BVH& bvh, const Ray& ray, 
     }
 }
 
-// CalculateRTShadow<true>, CommonLighting.hlsli:380-496.
-template <class BVH, class STACK>
-HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack)
+// ---- CalculateRTShadow<true>, CommonLighting.hlsli:380-496 ------------------------------------------------------
+// State carried from candidate to candidate (:404-407) and the per-candidate body (:409-470); returns true when the
+// candidate commits (the query then returns 0).
+struct ShadowState { float transmission; bool inVolume; float inVolumeStartT; f3 sigmaT; };
+
+HRT_DEV bool shadow_candidate(const SceneView& s, const Ray& ray, float hitT, uint32_t tri, float bu, float bv, ShadowState& st)
+{
+    TriVerts tv = load_tri_attr(s, tri);           // inst.m_LODIndex is 0 on this path (validated at upload), :423
+    const HrptMaterialConstants& mat = s.materials[tv.material];
+    f2 uv = interpolated_uv(tv, bu, bv);
+    if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
+        // AlphaTestGrad on single-mip textures == level-0 sample at the interpolated uv (RaytracingCommon.hlsli:112-130,207-240)
+        return candidate_alpha(s, mat, uv) >= mat.m_AlphaCutoff;
+    }
+    if (mat.m_AlphaMode != HRPT_ALPHA_MODE_BLEND) return true;
+    float alpha = candidate_alpha(s, mat, uv);
+    float opacity = hrt_saturate(alpha * (1.0f - mat.m_TransmissionFactor));
+    st.transmission *= (1.0f - opacity);
+    if (mat.m_TransmissionFactor > 0.0f && mat.m_IsThinSurface == 0) {
+        float w0 = (1.0f - bu) - bv;
+        f3 ln = (tv.n0 * w0 + tv.n1 * bu) + tv.n2 * bv;
+        f3 wn = normalize(transform_normal(ln, s.instShade[tv.inst]));
+        bool front = dot(wn, ray.d) < 0.0f;
+        if (front) { st.inVolume = true; st.inVolumeStartT = hitT; st.sigmaT = mk3(mat.m_SigmaA) + mk3(mat.m_SigmaS); }
+        else if (st.inVolume) {
+            float seg = hrt_max(0.0f, hitT - st.inVolumeStartT);
+            f3 tr = mk3(hrt_exp(-st.sigmaT.x * seg), hrt_exp(-st.sigmaT.y * seg), hrt_exp(-st.sigmaT.z * seg));
+            st.transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+            st.inVolume = false;
+        }
+    }
+    return st.transmission <= 1e-3f;
+}
+HRT_DEV float shadow_finish(const Ray& ray, ShadowState& st)                       // :477-495
+{
+    if (st.inVolume) {
+        float seg = hrt_max(0.0f, ray.tmax - st.inVolumeStartT);
+        f3 tr = mk3(hrt_exp(-st.sigmaT.x * seg), hrt_exp(-st.sigmaT.y * seg), hrt_exp(-st.sigmaT.z * seg));
+        st.transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+    }
+    return hrt_saturate(st.transmission);
+}
+HRT_DEV Ray shadow_ray(f3 worldPos, f3 L, float maxDist)                           // :391-396
 {
     const float kShadowBias = 0.01f;
     Ray ray; ray.o = worldPos; ray.d = L; ray.tmin = kShadowBias; ray.tmax = hrt_max(kShadowBias, maxDist - kShadowBias * 2.0f);
+    return ray;
+}
+
+// Re-trace form: one closest-hit query per non-opaque candidate (validation megakernel).
+template <class BVH, class STACK>
+HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack)
+{
+    Ray ray = shadow_ray(worldPos, L, maxDist);
     // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
     bool sawNonOpaque;
     if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque)) return 0.0f;
     if (!sawNonOpaque) return 1.0f;
-    // Non-opaque candidates, front to back.
-    float transmission = 1.0f; bool inVolume = false; float inVolumeStartT = 0.0f; f3 sigmaT = mk3(0.0f, 0.0f, 0.0f);
+    ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
     HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
-    for (;;) {
+    for (;;) {   // non-opaque candidates, front to back
         Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
         if (!h.valid) break;
-        TriVerts tv = load_tri_attr(s, h.tri);     // inst.m_LODIndex is 0 on this path (validated at upload), :423
-        const HrptMaterialConstants& mat = s.materials[tv.material];
-        f2 uv = interpolated_uv(tv, h.u, h.v);
-        if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
-            // AlphaTestGrad on single-mip textures == level-0 sample at the interpolated uv (RaytracingCommon.hlsli:112-130,207-240)
-            if (candidate_alpha(s, mat, uv) >= mat.m_AlphaCutoff) return 0.0f;
-        } else if (mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {
-            float alpha = candidate_alpha(s, mat, uv);
-            float opacity = hrt_saturate(alpha * (1.0f - mat.m_TransmissionFactor));
-            transmission *= (1.0f - opacity);
-            if (mat.m_TransmissionFactor > 0.0f && mat.m_IsThinSurface == 0) {
-                float w0 = (1.0f - h.u) - h.v;
-                f3 ln = (tv.n0 * w0 + tv.n1 * h.u) + tv.n2 * h.v;
-                f3 wn = normalize(transform_normal(ln, s.instShade[tv.inst]));
-                bool front = dot(wn, ray.d) < 0.0f;
-                if (front) { inVolume = true; inVolumeStartT = h.t; sigmaT = mk3(mat.m_SigmaA) + mk3(mat.m_SigmaS); }
-                else if (inVolume) {
-                    float seg = hrt_max(0.0f, h.t - inVolumeStartT);
-                    f3 tr = mk3(hrt_exp(-sigmaT.x * seg), hrt_exp(-sigmaT.y * seg), hrt_exp(-sigmaT.z * seg));
-                    transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
-                    inVolume = false;
-                }
-            }
-            if (transmission <= 1e-3f) return 0.0f;
-        } else return 0.0f;
+        if (shadow_candidate(s, ray, h.t, h.tri, h.u, h.v, st)) return 0.0f;
         lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
     }
-    if (inVolume) {
-        float seg = hrt_max(0.0f, ray.tmax - inVolumeStartT);
-        f3 tr = mk3(hrt_exp(-sigmaT.x * seg), hrt_exp(-sigmaT.y * seg), hrt_exp(-sigmaT.z * seg));
-        transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+    return shadow_finish(ray, st);
+}
+
+// Buffered form (wavefront shadow stage): the any-hit pass over opaque triangles also collects the K closest non-opaque
+// candidates, sorted by (t, inst, prim), into a per-lane buffer CAND (LDS columns of (t, triangle)); they are then processed front to
+// back without further traversals. More than K candidates: the re-trace loop continues behind the K-th. Same visiting
+// order as the re-trace form, hence the same result.
+template <int K, class BVH, class STACK, class CAND>
+HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, CAND& cand)
+{
+    Ray ray = shadow_ray(worldPos, L, maxDist);
+    if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
+    RayShear sh = make_shear(ray.d);
+    f3 inv = traversal_rcp(ray.d);
+    int sp = 0, count = 0; bool overflow = false;
+    int32_t cur;
+    if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
+    for (;;) {
+        while (cur >= 0) {
+            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
+            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
+            float tl, tr;
+            bool hl = slab(a, b, ray.o, inv, ray.tmin, ray.tmax, tl);
+            bool hr = slab(c, d, ray.o, inv, ray.tmin, ray.tmax, tr);
+            if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
+            else if (hl) cur = li;
+            else if (hr) cur = ri;
+            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+        }
+        if (cur == kTraversalDone) break;
+        uint32_t enc = (uint32_t)(~cur);
+        uint32_t first = enc >> 2, n = (enc & 3u) + 1u;
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 a, b, c; bvh.tri(first + i, a, b, c);
+            float t, u, v;
+            if (!tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, sh, t, u, v)) continue;
+            if (__float_as_uint(c.w) & 1u) return 0.0f;                           // opaque instance: committed
+            // insert (t, tri, u, v) keeping the K smallest keys sorted
+            uint32_t inst = __float_as_uint(a.w), prim = __float_as_uint(b.w);
+            int pos = count;
+            if (count == K) {
+                float lt; uint32_t ltri; cand.key(K - 1, lt, ltri);
+                float4 la, lb, lc; bvh.tri(ltri, la, lb, lc);
+                overflow = true;
+                if (!key_less(t, inst, prim, lt, __float_as_uint(la.w), __float_as_uint(lb.w))) continue;
+                pos = K - 1;
+            } else ++count;
+            while (pos > 0) {
+                float pt; uint32_t ptri; cand.key(pos - 1, pt, ptri);
+                bool less;
+                if (t != pt) less = t < pt;
+                else { float4 pa, pb, pc; bvh.tri(ptri, pa, pb, pc); less = key_less(t, inst, prim, pt, __float_as_uint(pa.w), __float_as_uint(pb.w)); }
+                if (!less) break;
+                cand.move(pos, pos - 1);
+                --pos;
+            }
+            cand.set(pos, t, first + i);
+        }
+        if (sp == 0) break;
+        cur = stack.pop(--sp);
     }
-    return hrt_saturate(transmission);
+    if (count == 0) return 1.0f;
+    ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
+    float lastT = 0.0f; uint32_t lastTri = 0;
+    for (int k = 0; k < count; ++k) {
+        float t; uint32_t tri; cand.key(k, t, tri);
+        float4 a, b, c; bvh.tri(tri, a, b, c);
+        float t2, u, v;
+        tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, sh, t2, u, v);   // recomputes (t, u, v) bit for bit
+        if (shadow_candidate(s, ray, t, tri, u, v, st)) return 0.0f;
+        lastT = t; lastTri = tri;
+    }
+    if (overflow) {   // more than K candidates: continue behind the K-th with the re-trace loop
+        float4 la, lb, lc; bvh.tri(lastTri, la, lb, lc);
+        HitKey lower; lower.have = true; lower.t = lastT; lower.inst = __float_as_uint(la.w); lower.prim = __float_as_uint(lb.w);
+        for (;;) {
+            Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+            if (!h.valid) break;
+            if (h.opaque) return 0.0f;
+            if (shadow_candidate(s, ray, h.t, h.tri, h.u, h.v, st)) return 0.0f;
+            lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
+        }
+    }
+    return shadow_finish(ray, st);
 }
 
 // One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908) in three stages, so that a schedule may run the

@@ -20,6 +20,7 @@ struct SceneTraits {
     bool hasTextures = false;          // some instanced material has m_TextureFlags != 0
     bool hasTransmissiveOrBlend = false;   // some instanced material takes the transmission branch (PathTracer.hlsl:149)
     bool directionalLightsOnly = true; // every GPULight is type 0
+    bool hasNonOpaque = false;         // some instance is ForceNonOpaque (material alpha mode MASK or BLEND)
     uint32_t bvhMaxDepth = 0;
 };
 

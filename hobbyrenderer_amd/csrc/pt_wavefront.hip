@@ -72,6 +72,15 @@ struct LdsStack {
     HRT_DEV void push(int sp, int32_t v) { base[(sp & (DEPTH - 1)) * kBlock] = v; }
     HRT_DEV int32_t pop(int sp) { return base[(sp & (DEPTH - 1)) * kBlock]; }
 };
+// per-lane buffer of the K closest non-opaque shadow candidates: (t, triangle) of entry k at base[(k*2 + {0,1}) * kBlock];
+// the barycentrics are recomputed from the triangle when the candidate is processed (same test => same bits)
+constexpr int kShadowCandidates = 8;
+struct LdsCandidates {
+    int32_t* base;
+    HRT_DEV void key(int k, float& t, uint32_t& tri) const { t = __int_as_float(base[(k * 2 + 0) * kBlock]); tri = (uint32_t)base[(k * 2 + 1) * kBlock]; }
+    HRT_DEV void set(int k, float t, uint32_t tri) { base[(k * 2 + 0) * kBlock] = __float_as_int(t); base[(k * 2 + 1) * kBlock] = (int32_t)tri; }
+    HRT_DEV void move(int dst, int src) { base[(dst * 2 + 0) * kBlock] = base[(src * 2 + 0) * kBlock]; base[(dst * 2 + 1) * kBlock] = base[(src * 2 + 1) * kBlock]; }
+};
 struct LdsBvh {
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
@@ -80,11 +89,11 @@ struct LdsBvh {
 
 // Carves dynamic LDS: [stack: DEPTH*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
 template <bool LDS_BVH, int DEPTH>
-HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh& lbvh)
+HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh& lbvh, size_t extraBytes = 0)
 {
     stack.base = reinterpret_cast<int32_t*>(smem) + threadIdx.x;
     if (LDS_BVH) {
-        float4* dst = reinterpret_cast<float4*>(smem + (size_t)DEPTH * kBlock * 4);
+        float4* dst = reinterpret_cast<float4*>(smem + (size_t)DEPTH * kBlock * 4 + extraBytes);
         const float4* srcN = reinterpret_cast<const float4*>(s.nodes);
         const float4* srcT = reinterpret_cast<const float4*>(s.tris);
         uint32_t nN = s.nodeCount * 4, nT = s.triCount * 3;
@@ -379,12 +388,15 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
 }
 
 // ------------------------------------------------------------------ shadow (NEE visibility + accumulation)
-template <bool LDS_BVH, int DEPTH, bool DIRONLY>
+// NONOPAQUE: the scene has ForceNonOpaque instances -> per-lane candidate buffer in LDS (after the stack) and the buffered query
+template <bool LDS_BVH, int DEPTH, bool DIRONLY, bool NONOPAQUE>
 __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStack<DEPTH> stack; LdsBvh lbvh;
-    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
+    constexpr size_t candBytes = NONOPAQUE ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh, candBytes);
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)DEPTH * kBlock * 4) + threadIdx.x;
     GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
@@ -409,8 +421,13 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     f3 L; float maxDist;
                     if (!nee_direction<DIRONLY>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ls.x, ls.y, L, maxDist)) continue;
                     float shadow;
-                    if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
-                    else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
+                    if (NONOPAQUE) {
+                        if (LDS_BVH) shadow = shadow_query_buffered<kShadowCandidates>(s, lbvh, origin, L, maxDist, stack, cand);
+                        else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
+                    } else {
+                        if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
+                        else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
+                    }
                     ++nRays;
                     if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped
                         float4 h2 = a.b.sh2[e], h3 = a.b.sh3[e];
@@ -464,10 +481,12 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 struct Variant { bool lds; int depth; };
 
 template <bool L, int D> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D>), g, dim3(kBlock), sh, st, a, parity); }
-template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly)
+template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
 {
-    if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<L, D, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    if (nonOpaque) {   // general variant (all light types) + candidate buffer
+        hipLaunchKernelGGL((wf_shadow<L, D, false, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
+    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, true, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<L, D, false, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
@@ -475,10 +494,10 @@ void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
     if (v.lds) { if (v.depth <= 8) launch_extend_t<true, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<true, 16>(g, sh, st, a, parity); else launch_extend_t<true, 32>(g, sh, st, a, parity); }
     else { if (v.depth <= 8) launch_extend_t<false, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<false, 16>(g, sh, st, a, parity); else launch_extend_t<false, 32>(g, sh, st, a, parity); }
 }
-void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly)
+void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
 {
-    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, cb, bounce, dirOnly); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, cb, bounce, dirOnly); else launch_shadow_t<true, 32>(g, sh, st, a, cb, bounce, dirOnly); }
-    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, cb, bounce, dirOnly); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, cb, bounce, dirOnly); else launch_shadow_t<false, 32>(g, sh, st, a, cb, bounce, dirOnly); }
+    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<true, 32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); }
+    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<false, 32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); }
 }
 
 } // namespace
@@ -589,7 +608,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : 32);
     const size_t bvhBytes = (size_t)scene.nodeCount * 64 + (size_t)scene.triCount * 48;
     const size_t stackBytes = (size_t)v.depth * kBlock * 4;
-    v.lds = bvhBytes > 0 && stackBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
+    const size_t candBytes = traits.hasNonOpaque ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    v.lds = bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
     const size_t traceLds = stackBytes + (v.lds ? bvhBytes : 0);
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 8;
 
@@ -629,7 +649,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
-            launch_shadow(v, dim3(grid), traceLds, stream, a, cb, bounce, traits.directionalLightsOnly);
+            launch_shadow(v, dim3(grid), traceLds, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
             if (timed) timing_mark(st, stream, 2, false);
         }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;

@@ -7,7 +7,7 @@ luts = native.precompute_atmosphere()
 sc, view, pos, cfg = scenes.config_cornell(luts, 1920, 1080)
 cb = scenes.fill_constants(view, pos, sc, 0, 4)
 ctxs = {}
-for shift in (8, 9, 10):
+for shift in (6, 7, 8, 9):
     os.environ["HRPT_WF_SEGMENT_SHIFT"] = str(shift)
     c = native.PathTracerContext(0); c.upload_scene(sc); c.resize(1920, 1080); ctxs[shift] = c
 tiles = {"full": (0, 0, 0, 0), "band135": (0, 405, 1920, 540)}
