@@ -119,6 +119,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     c->ownStream = c->stream;
     if (const char* e = getenv("HRPT_WF_SEGMENT_SHIFT")) c->wf.segmentShift = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     *out = c;
     return HRPT_OK;
 }

@@ -37,6 +37,7 @@ struct WavefrontState {
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
     bool profile = false;              // record HIP events around every extend / shade / shadow launch (HRPT_FRAME_PROFILE)
+    uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
     bool forceGlobalBvh = false;
     bool forceGeneralShade = false;

@@ -60,6 +60,7 @@ struct WfArgs {
     uint32_t maxLights;        // per-path light-sample slots in the shadow queue
     uint32_t hasMedium;        // scene has thick transmissive materials (medium state travels with the path)
     uint32_t hasStochasticAlpha;
+    uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     DeviceCounters* counters;
 };
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // Persistent while-while traversal with lane refill: a wave keeps up to 64 rays of its segment in flight; whenever
 // at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
-constexpr uint32_t kRefillMin = 12;
+constexpr uint32_t kRefillMinDefault = 12;
 
 template <bool LDS_BVH, int DEPTH>
 __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             // ---- refill idle lanes
             unsigned long long mIdle = __ballot(!active);
             uint32_t nIdle = (uint32_t)__popcll(mIdle);
-            if (next < cnt && (nIdle >= kRefillMin || nIdle == 64u)) {
+            if (next < cnt && (nIdle >= a.refillMin || nIdle == 64u)) {
                 uint32_t idx = next + prefix_rank(mIdle);
                 if (!active && idx < cnt) {
                     slot = segBase + idx;
@@ -599,6 +600,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
     a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
     a.counters = counters;
+    a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
 
     // ---- kernel variants and grids
     int dev = 0; hipDeviceProp_t prop;
@@ -611,7 +613,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const size_t candBytes = traits.hasNonOpaque ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     v.lds = bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
     const size_t traceLds = stackBytes + (v.lds ? bvhBytes : 0);
-    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 8;
+    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)
 
     const bool manyLights = maxLights > 1;
     const bool simpleScene = !traits.hasTextures && !traits.hasTransmissiveOrBlend && traits.directionalLightsOnly && !st.forceGeneralShade;
