@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <numeric>
 
 namespace hrt {
@@ -115,6 +116,48 @@ inline void transform_point(const float* p, const float* M, float* o)
     o[2] = ((p[0] * M[2] + p[1] * M[6]) + p[2] * M[10]) + M[14];
 }
 
+// ---- BVH2 -> BVH4 collapse: repeatedly replace the inner child with the largest box by its two children
+struct ChildRef { int32_t ref; float mn[3], mx[3]; };
+inline float box_area(const ChildRef& c)
+{
+    float dx = c.mx[0] - c.mn[0], dy = c.mx[1] - c.mn[1], dz = c.mx[2] - c.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+inline void children_of(const HostNode& n, ChildRef& l, ChildRef& r)
+{
+    l.ref = n.left; r.ref = n.right;
+    for (int k = 0; k < 3; ++k) { l.mn[k] = n.lmin[k]; l.mx[k] = n.lmax[k]; r.mn[k] = n.rmin[k]; r.mx[k] = n.rmax[k]; }
+}
+int32_t collapse4(const std::vector<HostNode>& n2, int32_t root2, std::vector<HostNode4>& out, uint32_t depth, uint32_t& maxDepth)
+{
+    maxDepth = std::max(maxDepth, depth);
+    ChildRef c[4]; int count = 2;
+    children_of(n2[(size_t)root2], c[0], c[1]);
+    while (count < 4) {
+        int best = -1; float bestArea = -1.0f;
+        for (int i = 0; i < count; ++i) if (c[i].ref >= 0) { float a = box_area(c[i]); if (a > bestArea) { bestArea = a; best = i; } }
+        if (best < 0) break;
+        ChildRef l, r; children_of(n2[(size_t)c[best].ref], l, r);
+        c[best] = l; c[count++] = r;
+    }
+    int32_t id = (int32_t)out.size();
+    out.emplace_back();
+    int32_t refs[4];
+    for (int i = 0; i < count; ++i) refs[i] = c[i].ref >= 0 ? collapse4(n2, c[i].ref, out, depth + 1, maxDepth) : c[i].ref;
+    HostNode4& n = out[(size_t)id];
+    // an unused slot holds a degenerate box far outside any ray interval (|inv| >= 1 and tmax = 1e10), so the slab test
+    // rejects it without a special case
+    const float far = 1e30f;
+    for (int i = 0; i < 4; ++i) {
+        bool used = i < count;
+        n.minx[i] = used ? c[i].mn[0] : far; n.miny[i] = used ? c[i].mn[1] : far; n.minz[i] = used ? c[i].mn[2] : far;
+        n.maxx[i] = used ? c[i].mx[0] : far; n.maxy[i] = used ? c[i].mx[1] : far; n.maxz[i] = used ? c[i].mx[2] : far;
+        n.child[i] = used ? refs[i] : kEmptyChild;
+        n.pad[i] = 0;
+    }
+    return id;
+}
+
 inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 inline void cross3(const float* a, const float* b, float* o)
 {
@@ -220,6 +263,7 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     Box root;
     int32_t r = b.build(0, (uint32_t)tris.size(), 0, root);
     if (r < 0) { out.rootLeaf = r; out.nodes.clear(); }
+    else { out.nodes4.reserve(out.nodes.size() / 2 + 1); collapse4(out.nodes, 0, out.nodes4, 0, out.maxDepth4); }
 
     // shading attributes in leaf order
     bool needTangents = false;

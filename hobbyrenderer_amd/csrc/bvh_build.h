@@ -29,6 +29,15 @@ struct HostTri {            // mirrors hrt::GpuTri, 48 B
     float p1[3]; uint32_t prim;
     float p2[3]; uint32_t flags;
 };
+// 4-wide node for the wavefront kernels (collapsed from the BVH2): child boxes in SoA (x of 4 children, y, z, ...) so
+// the four slab tests are data-parallel; 128 B = two cache lines fetched together. Empty slots: min = +inf, max = -inf.
+struct HostNode4 {
+    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    int32_t child[4];               // >= 0 inner node4 index, < 0 leaf (same encoding as HostNode), kEmptyChild = unused slot
+    uint32_t pad[4];
+};
+constexpr int32_t kEmptyChild = 0x7fffffff;
+
 // Shading attributes of one world triangle, unpacked ONCE at upload with exactly the arithmetic of UnpackVertex
 // (src/shaders/MeshCommon.hlsli:9-22): what GetTriangleVertices + UnpackVertex (RaytracingCommon.hlsli:33-50)
 // would produce per hit. 80 B, same (leaf) order as HostTri, so a hit is one index into both arrays.
@@ -43,10 +52,13 @@ struct HostTriAttr {
 struct HostTriTangent { float t0[4], t1[4], t2[4]; };   // DecodeOct tangents + sign, only built when a normal map exists
 // MakeAdjugateMatrix(world) rows (Common.hlsli:33-41), computed once per instance with the same cross products.
 struct HostInstShade { float adj0[4], adj1[4], adj2[4]; };
+static_assert(sizeof(HostNode4) == 128, "GPU layouts");
 static_assert(sizeof(HostNode) == 64 && sizeof(HostTri) == 48 && sizeof(HostTriAttr) == 80 && sizeof(HostInstShade) == 48, "GPU layouts");
 
 struct BuiltBvh {
     std::vector<HostNode> nodes;    // empty when the scene fits one leaf
+    std::vector<HostNode4> nodes4;  // the same tree collapsed to 4-wide nodes (root = 0); empty when nodes is empty
+    uint32_t maxDepth4 = 0;         // depth of the 4-wide tree; a traversal stack needs at most 3 * maxDepth4 + 1 entries
     std::vector<HostTri> tris;      // leaf order
     std::vector<HostTriAttr> attrs; // parallel to tris
     std::vector<HostTriTangent> tangents; // parallel to tris, empty unless some material samples a normal map

@@ -120,6 +120,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_SEGMENT_SHIFT")) c->wf.segmentShift = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
     *out = c;
     return HRPT_OK;
 }
@@ -172,6 +173,9 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
     v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
     v.rootLeaf = bvh.rootLeaf;
+    const HostNode4* dn4;
+    if ((r = upload(c, bvh.nodes4.data(), bvh.nodes4.size(), &dn4)) != HRPT_OK) return r;
+    v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)bvh.nodes4.size();
     // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
     // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
     const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
@@ -212,7 +216,7 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     c->view = v; c->haveScene = true;
     c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
     c->traits = SceneTraits();
-    c->traits.bvhMaxDepth = bvh.maxDepth;
+    c->traits.bvhMaxDepth = bvh.maxDepth; c->traits.bvh4MaxDepth = bvh.maxDepth4;
     for (uint32_t i = 0; i < s->instanceCount; ++i) {
         const HrptMaterialConstants& m = s->materials[s->instances[i].m_MaterialIndex];
         if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;

@@ -63,6 +63,9 @@ struct GpuNode {            // 64 B: both child boxes live in the parent -> one 
     float rmin[3]; uint32_t pad0;
     float rmax[3]; uint32_t pad1;
 };
+struct GpuNode4 {           // 128 B: four child boxes in SoA + four child refs (bvh_build.h HostNode4); empty slot = far-away box
+    float4 minx, miny, minz, maxx, maxy, maxz; int4 child; uint4 pad;
+};
 struct GpuTri {             // 48 B world-space triangle (instance transform applied at upload)
     float p0[3]; uint32_t inst;
     float p1[3]; uint32_t prim;
@@ -76,6 +79,7 @@ struct GpuTexture { const uint8_t* rgba8; uint32_t w, h; };
 
 struct SceneView {
     const GpuNode* nodes; uint32_t nodeCount;
+    const GpuNode4* nodes4; uint32_t node4Count;   // the same tree collapsed to 4-wide nodes (wavefront kernels); root = 0
     const GpuTri* tris; uint32_t triCount;
     int32_t rootLeaf;       // when the whole scene fits one leaf: encoded leaf, else 0
     const GpuTriAttr* attrs;            // parallel to tris
@@ -141,11 +145,28 @@ HRT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& r, const RayShear& s, floa
 
 // Node/triangle fetch policy: the BVH is read either from HBM/L2 (global) or from an LDS copy.
 struct GlobalBvh {
+    static constexpr int kWidth = 2;
     const GpuNode* nodes; const GpuTri* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const
     {
         const float4* p = reinterpret_cast<const float4*>(nodes + i);
         a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    }
+    HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
+    {
+        const float4* p = reinterpret_cast<const float4*>(tris + i);
+        a = p[0]; b = p[1]; c = p[2];
+    }
+};
+
+struct GlobalBvh4 {
+    static constexpr int kWidth = 4;
+    const GpuNode4* nodes; const GpuTri* tris;
+    HRT_DEV void node4(int i, float4& mnx, float4& mny, float4& mnz, float4& mxx, float4& mxy, float4& mxz, int4& ch) const
+    {
+        const float4* p = reinterpret_cast<const float4*>(nodes + i);
+        mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5];
+        float4 c = p[6]; ch = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
     }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
     {
@@ -172,6 +193,57 @@ HRT_DEV bool slab(float4 bmin, float4 bmax, f3 o, f3 inv, float t0, float t1, fl
 
 constexpr int32_t kTraversalDone = (int32_t)0x80000000;   // not a valid leaf encoding (first < 2^29)
 
+// one box of a 4-wide node: entry distance, or +inf on a miss
+HRT_DEV float slab1(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 o, f3 inv, float t0, float t1)
+{
+    float tx0 = (bminx - o.x) * inv.x, tx1 = (bmaxx - o.x) * inv.x;
+    float ty0 = (bminy - o.y) * inv.y, ty1 = (bmaxy - o.y) * inv.y;
+    float tz0 = (bminz - o.z) * inv.z, tz1 = (bmaxz - o.z) * inv.z;
+    float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), t0));
+    float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fminf(__builtin_fmaxf(tz0, tz1), t1));
+    bool hit = __builtin_fmaf(-__builtin_fabsf(lo), 2e-6f, lo) <= __builtin_fmaf(__builtin_fabsf(hi), 2e-6f, hi);
+    return hit ? lo : __builtin_inff();
+}
+HRT_DEV void cswap(float& ta, int32_t& ra, float& tb, int32_t& rb)
+{
+    bool sw = tb < ta;
+    float t = sw ? tb : ta; tb = sw ? ta : tb; ta = t;
+    int32_t r = sw ? rb : ra; rb = sw ? ra : rb; ra = r;
+}
+
+// One traversal step from inner node `cur`: tests its child boxes against [tmin, tlim], pushes the far hits (nearest on
+// top) and returns the next node reference: the nearest hit child, else the popped stack top, else kTraversalDone.
+template <class BVH, class STACK>
+HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 o, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
+{
+    if constexpr (BVH::kWidth == 2) {
+        float4 a, b, c, d; bvh.node(cur, a, b, c, d);
+        int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
+        float tl, tr;
+        bool hl = slab(a, b, o, inv, tmin, tlim, tl);
+        bool hr = slab(c, d, o, inv, tmin, tlim, tr);
+        if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); return leftFirst ? li : ri; }
+        if (hl) return li;
+        if (hr) return ri;
+        return (sp == 0) ? kTraversalDone : stack.pop(--sp);
+    } else {
+        float4 mnx, mny, mnz, mxx, mxy, mxz; int4 ch;
+        bvh.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, ch);
+        float t0 = slab1(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, inv, tmin, tlim);
+        float t1 = slab1(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, inv, tmin, tlim);
+        float t2 = slab1(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, inv, tmin, tlim);
+        float t3 = slab1(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, inv, tmin, tlim);
+        int32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+        cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
+        const float inf = __builtin_inff();
+        if (t3 < inf) stack.push(sp++, r3);
+        if (t2 < inf) stack.push(sp++, r2);
+        if (t1 < inf) stack.push(sp++, r1);
+        if (t0 < inf) return r0;
+        return (sp == 0) ? kTraversalDone : stack.pop(--sp);
+    }
+}
+
 HRT_DEV f3 traversal_rcp(f3 d)
 {
     return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
@@ -193,20 +265,7 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     else cur = 0;
     float tlim = r.tmax;               // == best.t once a hit exists
     for (;;) {
-        while (cur >= 0) {
-            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
-            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
-            float tl, tr;
-            bool hl = slab(a, b, r.o, inv, r.tmin, tlim, tl);
-            bool hr = slab(c, d, r.o, inv, r.tmin, tlim, tr);
-            if (hl && hr) {
-                bool leftFirst = tl <= tr;
-                stack.push(sp++, leftFirst ? ri : li);
-                cur = leftFirst ? li : ri;
-            } else if (hl) cur = li;
-            else if (hr) cur = ri;
-            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
-        }
+        while (cur >= 0) cur = inner_step(bvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
         if (cur == kTraversalDone) break;
         {
             uint32_t enc = (uint32_t)(~cur);
@@ -243,17 +302,7 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
     else cur = 0;
     for (;;) {
-        while (cur >= 0) {
-            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
-            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
-            float tl, tr;
-            bool hl = slab(a, b, r.o, inv, r.tmin, r.tmax, tl);
-            bool hr = slab(c, d, r.o, inv, r.tmin, r.tmax, tr);
-            if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
-            else if (hl) cur = li;
-            else if (hr) cur = ri;
-            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
-        }
+        while (cur >= 0) cur = inner_step(bvh, cur, r.o, inv, r.tmin, r.tmax, stack, sp);
         if (cur == kTraversalDone) break;
         {
             uint32_t enc = (uint32_t)(~cur);

@@ -161,17 +161,7 @@ HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 world
     int32_t cur;
     if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
     for (;;) {
-        while (cur >= 0) {
-            float4 a, b, c, d; bvh.node(cur, a, b, c, d);
-            int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
-            float tl, tr;
-            bool hl = slab(a, b, ray.o, inv, ray.tmin, ray.tmax, tl);
-            bool hr = slab(c, d, ray.o, inv, ray.tmin, ray.tmax, tr);
-            if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
-            else if (hl) cur = li;
-            else if (hr) cur = ri;
-            else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
-        }
+        while (cur >= 0) cur = inner_step(bvh, cur, ray.o, inv, ray.tmin, ray.tmax, stack, sp);
         if (cur == kTraversalDone) break;
         uint32_t enc = (uint32_t)(~cur);
         uint32_t first = enc >> 2, n = (enc & 3u) + 1u;

@@ -22,6 +22,7 @@ struct SceneTraits {
     bool directionalLightsOnly = true; // every GPULight is type 0
     bool hasNonOpaque = false;         // some instance is ForceNonOpaque (material alpha mode MASK or BLEND)
     uint32_t bvhMaxDepth = 0;
+    uint32_t bvh4MaxDepth = 0;
 };
 
 struct WavefrontState {
@@ -40,6 +41,7 @@ struct WavefrontState {
     uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
     bool forceGlobalBvh = false;
+    uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
 };
 

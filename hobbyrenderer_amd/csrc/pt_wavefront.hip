@@ -82,22 +82,34 @@ struct LdsCandidates {
     HRT_DEV void set(int k, float t, uint32_t tri) { base[(k * 2 + 0) * kBlock] = __float_as_int(t); base[(k * 2 + 1) * kBlock] = (int32_t)tri; }
     HRT_DEV void move(int dst, int src) { base[(dst * 2 + 0) * kBlock] = base[(src * 2 + 0) * kBlock]; base[(dst * 2 + 1) * kBlock] = base[(src * 2 + 1) * kBlock]; }
 };
+// BVH copy in LDS; W = node width (2: GpuNode, 4: GpuNode4)
+template <int W>
 struct LdsBvh {
+    static constexpr int kWidth = W;
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+    HRT_DEV void node4(int i, float4& mnx, float4& mny, float4& mnz, float4& mxx, float4& mxy, float4& mxz, int4& ch) const
+    {
+        const float4* p = nodes + 8 * i;
+        mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5];
+        float4 c = p[6]; ch = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
+    }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
 };
+template <int W> struct GlobalBvhOf;
+template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV GlobalBvh make(const SceneView& s) { GlobalBvh g; g.nodes = s.nodes; g.tris = s.tris; return g; } };
+template <> struct GlobalBvhOf<4> { using type = GlobalBvh4; static HRT_DEV GlobalBvh4 make(const SceneView& s) { GlobalBvh4 g; g.nodes = s.nodes4; g.tris = s.tris; return g; } };
 
 // Carves dynamic LDS: [stack: DEPTH*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
-template <bool LDS_BVH, int DEPTH>
-HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh& lbvh, size_t extraBytes = 0)
+template <bool LDS_BVH, int DEPTH, int W>
+HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh<W>& lbvh, size_t extraBytes = 0)
 {
     stack.base = reinterpret_cast<int32_t*>(smem) + threadIdx.x;
     if (LDS_BVH) {
         float4* dst = reinterpret_cast<float4*>(smem + (size_t)DEPTH * kBlock * 4 + extraBytes);
-        const float4* srcN = reinterpret_cast<const float4*>(s.nodes);
+        const float4* srcN = W == 2 ? reinterpret_cast<const float4*>(s.nodes) : reinterpret_cast<const float4*>(s.nodes4);
         const float4* srcT = reinterpret_cast<const float4*>(s.tris);
-        uint32_t nN = s.nodeCount * 4, nT = s.triCount * 3;
+        uint32_t nN = W == 2 ? s.nodeCount * 4 : s.node4Count * 8, nT = s.triCount * 3;
         for (uint32_t i = threadIdx.x; i < nN; i += kBlock) dst[i] = srcN[i];
         for (uint32_t i = threadIdx.x; i < nT; i += kBlock) dst[nN + i] = srcT[i];
         lbvh.nodes = dst; lbvh.tris = dst + nN;
@@ -192,13 +204,13 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
 constexpr uint32_t kRefillMinDefault = 12;
 
-template <bool LDS_BVH, int DEPTH>
+template <bool LDS_BVH, int DEPTH, int W>
 __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStack<DEPTH> stack; LdsBvh lbvh;
-    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh);
-    GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+    LdsStack<DEPTH> stack; LdsBvh<W> lbvh;
+    setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh);
+    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
 
     const uint32_t wavesPerBlock = kBlock / 64;
@@ -242,16 +254,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             if (active) {
                 // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
                 while (cur >= 0) {
-                    float4 na, nb, nc, nd;
-                    if (LDS_BVH) lbvh.node(cur, na, nb, nc, nd); else gbvh.node(cur, na, nb, nc, nd);
-                    int32_t li = __float_as_int(na.w), ri = __float_as_int(nb.w);
-                    float tl, tr;
-                    bool hl = slab(na, nb, r.o, inv, r.tmin, tlim, tl);
-                    bool hr = slab(nc, nd, r.o, inv, r.tmin, tlim, tr);
-                    if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); cur = leftFirst ? li : ri; }
-                    else if (hl) cur = li;
-                    else if (hr) cur = ri;
-                    else cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+                    if (LDS_BVH) cur = inner_step(lbvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
+                    else cur = inner_step(gbvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
                 }
                 // ---- intersect the leaf
                 if (cur != kTraversalDone) {
@@ -390,15 +394,15 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
 
 // ------------------------------------------------------------------ shadow (NEE visibility + accumulation)
 // NONOPAQUE: the scene has ForceNonOpaque instances -> per-lane candidate buffer in LDS (after the stack) and the buffered query
-template <bool LDS_BVH, int DEPTH, bool DIRONLY, bool NONOPAQUE>
+template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, bool NONOPAQUE>
 __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStack<DEPTH> stack; LdsBvh lbvh;
+    LdsStack<DEPTH> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = NONOPAQUE ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
-    setup_lds<LDS_BVH, DEPTH>(smem, a.scene, stack, lbvh, candBytes);
+    setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)DEPTH * kBlock * 4) + threadIdx.x;
-    GlobalBvh gbvh; gbvh.nodes = a.scene.nodes; gbvh.tris = a.scene.tris;
+    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
     const float sunIntensity = s.lights[0].m_Intensity;      // g_Lights[0], PathTracer.hlsl:137 (reference quirk kept)
@@ -479,26 +483,41 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 }
 
 // ------------------------------------------------------------------ host side
-struct Variant { bool lds; int depth; };
+struct Variant { bool lds; int depth; int width; size_t ldsBytes; };
 
-template <bool L, int D> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D>), g, dim3(kBlock), sh, st, a, parity); }
-template <bool L, int D> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
+template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D, W>), g, dim3(kBlock), sh, st, a, parity); }
+template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
 {
     if (nonOpaque) {   // general variant (all light types) + candidate buffer
-        hipLaunchKernelGGL((wf_shadow<L, D, false, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
-    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, true, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<L, D, false, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+        hipLaunchKernelGGL((wf_shadow<L, D, W, false, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
+    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<L, D, W, false, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
+// stack depths: BVH2 8/16/32 (needs maxDepth + 2), BVH4 16/32/64 (needs 3 * maxDepth4 + 2)
+template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
+{
+    if (v.width == 2) {
+        if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity); else launch_extend_t<L, 32, 2>(g, sh, st, a, parity);
+    } else {
+        if (v.depth <= 16) launch_extend_t<L, 16, 4>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_t<L, 32, 4>(g, sh, st, a, parity); else launch_extend_t<L, 64, 4>(g, sh, st, a, parity);
+    }
+}
+template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
+{
+    if (v.width == 2) {
+        if (v.depth <= 8) launch_shadow_t<L, 8, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<L, 16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+    } else {
+        if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+    }
+}
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
 {
-    if (v.lds) { if (v.depth <= 8) launch_extend_t<true, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<true, 16>(g, sh, st, a, parity); else launch_extend_t<true, 32>(g, sh, st, a, parity); }
-    else { if (v.depth <= 8) launch_extend_t<false, 8>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<false, 16>(g, sh, st, a, parity); else launch_extend_t<false, 32>(g, sh, st, a, parity); }
+    if (v.lds) launch_extend_l<true>(v, g, sh, st, a, parity); else launch_extend_l<false>(v, g, sh, st, a, parity);
 }
 void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
 {
-    if (v.lds) { if (v.depth <= 8) launch_shadow_t<true, 8>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<true, 16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<true, 32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); }
-    else { if (v.depth <= 8) launch_shadow_t<false, 8>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<false, 16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<false, 32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); }
+    if (v.lds) launch_shadow_l<true>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_l<false>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
 }
 
 } // namespace
@@ -606,13 +625,26 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     int dev = 0; hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
-    Variant v;
-    v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : 32);
-    const size_t bvhBytes = (size_t)scene.nodeCount * 64 + (size_t)scene.triCount * 48;
-    const size_t stackBytes = (size_t)v.depth * kBlock * 4;
+    // Node width per kernel class (measured, scripts/gpu_bvh4_ab.sh): the 4-wide tree wins for closest-hit queries everywhere
+    // (fewer, fuller steps: -9..-11% extend time on configs 2/4/5) and for shadow queries that buffer non-opaque candidates or
+    // read the BVH from global memory (-9..-14%); the small opaque any-hit kernel over an LDS-resident BVH is faster 2-wide
+    // (the 4-wide step costs it 12 VGPRs = one wave of occupancy).
     const size_t candBytes = traits.hasNonOpaque ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
-    v.lds = bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
-    const size_t traceLds = stackBytes + (v.lds ? bvhBytes : 0);
+    auto pick = [&](int width, size_t extraBytes) {
+        Variant v; v.width = width;
+        if (v.width == 4 && 3 * traits.bvh4MaxDepth + 2 > 64) v.width = 2;
+        if (v.width == 2) v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : 32);
+        else v.depth = 3 * traits.bvh4MaxDepth + 2 <= 16 ? 16 : (3 * traits.bvh4MaxDepth + 2 <= 32 ? 32 : 64);
+        const size_t bvhBytes = (v.width == 2 ? (size_t)scene.nodeCount * 64 : (size_t)scene.node4Count * 128) + (size_t)scene.triCount * 48;
+        const size_t stackBytes = (size_t)v.depth * kBlock * 4;
+        v.lds = bvhBytes > 0 && stackBytes + extraBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
+        v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0);
+        return v;
+    };
+    const int forced = st.bvhWidth == 2 ? 2 : (st.bvhWidth == 4 ? 4 : 0);
+    const Variant vE = pick(forced ? forced : 4, 0);
+    Variant vS = pick(forced ? forced : 4, candBytes);
+    if (!forced && vS.lds && !traits.hasNonOpaque) vS = pick(2, candBytes);
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)
 
     const bool manyLights = maxLights > 1;
@@ -644,14 +676,14 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             const uint32_t parity = (uint32_t)bounce & 1u;
             const bool timed = st.profile && st.eventsUsed + 6 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
-            launch_extend(v, dim3(grid), traceLds, stream, a, parity);
+            launch_extend(vE, dim3(grid), vE.ldsBytes, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
-            launch_shadow(v, dim3(grid), traceLds, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+            launch_shadow(vS, dim3(grid), vS.ldsBytes, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
             if (timed) timing_mark(st, stream, 2, false);
         }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;

@@ -157,6 +157,24 @@ def test_config5_glass_stress_reduced(ctx, luts, flags):
     _assert_parity(*_run_both(ctx, sc, view, pos, 160, 90, 4, cfg["max_bounces"], flags))
 
 
+@pytest.mark.parametrize("width", [2, 4])
+def test_forced_bvh_width(luts, width, monkeypatch):
+    """The trace kernels traverse the 2-wide tree or its 4-wide collapse (HRPT_WF_BVH_WIDTH, read at hrpt_create): the hit
+    definition is BVH-independent, so both are bit-exact against the oracle -- LDS and global BVH, opaque and buffered shadows."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    monkeypatch.setenv("HRPT_WF_BVH_WIDTH", str(width))
+    c = PathTracerContext(0)
+    try:
+        sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=0.5, tex_size=32)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+    finally:
+        c.close()
+
+
 # ---- edge cases: empty / tiny scenes, odd sizes, unaligned tiles, spp batching, big BVH -------------------------
 def _empty_scene(luts):
     b = scenes.SceneBuilder()
