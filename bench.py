@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal only: all ranks share GPU 0 and the all-gather runs over gloo through host memory; the printed value is NOT a result")
+    ap.add_argument("--serial-gather", action="store_true", help="N>1: all-gather in stream order after each render instead of overlapping it with the next frame")
+    ap.add_argument("--force-sharded", action="store_true", help="testing: run the N>1 code path (RCCL all-gather, comm stream) with a single rank")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json config: 2 = headline (Cornell-class), 4 = Sponza-class stand-in, 5 = glass stress stand-in")
     args = ap.parse_args()
@@ -77,8 +79,12 @@ def main():
     rehearse = args.rehearse_on_one_gpu
     if rehearse:
         local_rank = 0
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -103,11 +109,11 @@ def main():
     flags = {"default": S.FRAME_DEFAULT, "megakernel": S.FRAME_MEGAKERNEL, "wavefront": S.FRAME_WAVEFRONT}[args.mode]
 
     # row-band sharding (hobbyrenderer_amd/distributed.py); bands are contiguous in the row-major accumulation image
-    from hobbyrenderer_amd.distributed import band_for_rank, device_tensor, render_sharded
+    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank, device_tensor, render_sharded
     y0, y1 = band_for_rank(H, world, rank)
     rows = y1 - y0
     accum_ptr, _ = ctx.device_images()
-    full = device_tensor(accum_ptr, (H, W, 4), dev) if world > 1 else None
+    full = device_tensor(accum_ptr, (H, W, 4), dev) if sharded else None
 
     def all_gather(full_t, band_t):
         if not rehearse:
@@ -117,7 +123,8 @@ def main():
             dist.all_gather_into_tensor(host, band_t.cpu())
             full_t.copy_(host)
 
-    same_stream = world > 1 and not rehearse
+    same_stream = sharded and not rehearse
+    pipelined = same_stream and not args.serial_gather
     if same_stream:
         # render, band clone, RCCL all-gather and resolve are all ordered on torch's current stream: no host sync in a step
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -127,9 +134,17 @@ def main():
         if not same_stream:
             ctx.synchronize()                                   # library stream -> host before the host-staged gather
 
+    frames = None
+    if pipelined:
+        # frame k's all-gather + resolve run on a second stream while frame k+1 renders (hobbyrenderer_amd/distributed.py)
+        frames = PipelinedFrames(render_band, full[y0:y1], H, W, rank, world, all_gather,
+                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), H * W, stream), dev)
+
     def step():
-        if world == 1:
+        if not sharded:
             ctx.render(cb, accum_count=spp, flags=flags)
+        elif pipelined:
+            frames.submit()
         else:
             render_sharded(render_band, full, rank, world, all_gather)                   # the single collective
             if not same_stream:
@@ -137,9 +152,11 @@ def main():
             ctx.resolve_output()                                # Output = accum.rgb / accum.a on every rank
 
     def sync_all():
+        if frames is not None:
+            frames.finish()
         ctx.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -156,18 +173,18 @@ def main():
     st = ctx.stats()
     # per-kernel-class device times: a few extra steps with HRPT_FRAME_PROFILE (events around every launch), outside the timed region
     prof_steps = 0
-    if world == 1 and args.mode != "megakernel":
+    if args.mode != "megakernel":
         prof_steps = 3
         ctx.reset_stats()
         for _ in range(prof_steps):
-            ctx.render(cb, accum_count=spp, flags=flags | S.FRAME_PROFILE)
+            ctx.render(cb, accum_count=spp, tile=(0, y0, W, y1) if sharded else (0, 0, 0, 0), flags=flags | S.FRAME_PROFILE)
         ctx.synchronize()
         pst = ctx.stats()
 
     red_dev = torch.device("cpu") if rehearse else dev
     tm = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     rays = torch.tensor([float(st.closestRays + st.shadowRays), float(st.closestRays), float(st.shadowRays)], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tm.item())
@@ -182,7 +199,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not rehearse else "REHEARSAL on one GPU (gloo through host): not a result",
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
-                       "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" if world > 1 else ""),
+                       "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
         }
@@ -211,7 +228,7 @@ def main():
         b_closest = 768.0 + 32.0 * n_c + 48.0 * t_c
         b_shadow = 36.0 + 32.0 * n_s + 48.0 * t_s
         r0_closest, r0_shadow = float(st.closestRays) / args.steps, float(st.shadowRays) / args.steps   # rank 0, per step
-        px0 = (y1 - y0) * W if world > 1 else W * H
+        px0 = (y1 - y0) * W if sharded else W * H
         step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
         if prof_steps and pst.traceKernelLaunches > 0:
             # wavefront: per-class device time from HIP events the library records on ITS stream around every launch.
@@ -247,7 +264,7 @@ def main():
                               "n_closest": n_c, "t_closest": t_c, "n_shadow": n_s, "t_shadow": t_s}
         print(json.dumps(result))
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

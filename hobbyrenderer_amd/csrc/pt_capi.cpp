@@ -121,6 +121,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
     *out = c;
     return HRPT_OK;
 }
@@ -352,6 +353,18 @@ int hrpt_resolve_output(HrptContext* c)
     if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_output: hrpt_resize not called");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_resolve(c->dAccum, c->dOutput, c->width * c->height, c->stream));
+    return HRPT_OK;
+}
+
+int hrpt_resolve_device(HrptContext* c, const float* accumulationDevice, float* outputDevice, uint64_t pixelCount, void* stream)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!accumulationDevice || !outputDevice) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_device: null image");
+    if (pixelCount == 0) return HRPT_OK;
+    if (pixelCount > 0xFFFFFFFFull) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_device: image too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_resolve(reinterpret_cast<const float4*>(accumulationDevice), reinterpret_cast<float4*>(outputDevice), (uint32_t)pixelCount,
+                              static_cast<hipStream_t>(stream)));
     return HRPT_OK;
 }
 

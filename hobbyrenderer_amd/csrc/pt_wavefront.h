@@ -41,6 +41,10 @@ struct WavefrontState {
     uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
     bool forceGlobalBvh = false;
+    bool serialShadow = false;         // true: wf_shadow runs in stream order instead of concurrently with the next wf_extend
+    // second stream + fork/join events: wf_shadow(b) overlaps wf_extend(b+1) (they share no buffer)
+    hipStream_t auxStream = nullptr;
+    std::vector<hipEvent_t> forkEvents, joinEvents;
     uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
 };

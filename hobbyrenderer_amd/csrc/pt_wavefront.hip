@@ -534,6 +534,11 @@ void wavefront_release(WavefrontState& st)
     st.pool = nullptr; st.poolBytes = 0;
     for (hipEvent_t e : st.events) (void)hipEventDestroy(e);
     st.events.clear(); st.eventsUsed = 0;
+    for (hipEvent_t e : st.forkEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : st.joinEvents) (void)hipEventDestroy(e);
+    st.forkEvents.clear(); st.joinEvents.clear();
+    if (st.auxStream) (void)hipStreamDestroy(st.auxStream);
+    st.auxStream = nullptr;
 }
 
 void wavefront_collect_timing(WavefrontState& st)
@@ -672,20 +677,44 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         }
         hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
         const int maxBounces = (int)cb.m_MaxBounces;
+        // wf_shadow(b) only reads the shadow queue of shade(b) and adds into sampleRadiance; wf_extend(b+1) reads the path queue and
+        // writes hit records: no shared buffer, so the two run concurrently (fork after shade(b), join before shade(b+1), which both
+        // rewrites the shadow queue and adds the next radiance term -- the per-sample order of additions is unchanged).
+        // Per-launch timing (HRPT_FRAME_PROFILE) needs stream order, so profiling renders serially.
+        bool overlap = !st.profile && !st.serialShadow && maxBounces > 1;
+        if (overlap) {
+            if (!st.auxStream && hipStreamCreateWithFlags(&st.auxStream, hipStreamNonBlocking) != hipSuccess) { st.auxStream = nullptr; overlap = false; }
+            while (overlap && st.forkEvents.size() < (size_t)maxBounces) {
+                hipEvent_t f, j;
+                if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess) { overlap = false; break; }
+                if (hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(f); overlap = false; break; }
+                st.forkEvents.push_back(f); st.joinEvents.push_back(j);
+            }
+        }
+        bool pendingJoin = false;
         for (int bounce = 0; bounce < maxBounces; ++bounce) {
             const uint32_t parity = (uint32_t)bounce & 1u;
             const bool timed = st.profile && st.eventsUsed + 6 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
             launch_extend(vE, dim3(grid), vE.ldsBytes, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
+            if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
-            launch_shadow(vS, dim3(grid), vS.ldsBytes, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+            if (overlap) {
+                if ((e = hipEventRecord(st.forkEvents[(size_t)bounce], stream)) != hipSuccess || (e = hipStreamWaitEvent(st.auxStream, st.forkEvents[(size_t)bounce], 0)) != hipSuccess) { error = "fork to the shadow stream"; return e; }
+                launch_shadow(vS, dim3(grid), vS.ldsBytes, st.auxStream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+                if ((e = hipEventRecord(st.joinEvents[(size_t)bounce], st.auxStream)) != hipSuccess) { error = "hipEventRecord(join)"; return e; }
+                pendingJoin = true;
+            } else {
+                launch_shadow(vS, dim3(grid), vS.ldsBytes, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+            }
             if (timed) timing_mark(st, stream, 2, false);
         }
+        if (pendingJoin && (e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)maxBounces - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;
         hipLaunchKernelGGL(wf_resolve, dim3(rgrid), dim3(kBlock), 0, stream, a, accumulation, output, cb.m_AccumulationIndex);
         if ((e = hipGetLastError()) != hipSuccess) { error = "kernel launch"; return e; }

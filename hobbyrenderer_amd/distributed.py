@@ -45,3 +45,66 @@ def device_tensor(ptr, shape, device):
     """torch view of a float32 device buffer owned by libhobbyrt_pt.so (the accumulation / output images)."""
     import torch
     return torch.as_tensor(_DevMem(ptr, shape), device=device)
+
+
+class PipelinedFrames:
+    """Sharded frames with the all-gather of frame k overlapped with the render of frame k+1.
+
+    Per rank: the path-tracer context renders its row band into the context's accumulation image on the compute stream;
+    the band is copied (device to device, 16 B/pixel) into one of two staging buffers; a second stream (`comm`) waits for
+    that copy, runs the single RCCL all-gather into one of two full-size `gathered` images and resolves Output = rgb / a
+    (hrpt_resolve_device) into the matching `output` image. The compute stream only waits for the comm stream when it is
+    about to reuse a staging/gathered pair (two frames later), so a frame's xGMI traffic hides behind the next render.
+    finish() joins both streams. On CPU (gloo tests) the same bookkeeping runs without streams.
+
+    render_band(y0, y1): enqueues the band render on the CURRENT torch stream (the context must be bound to it with
+                         hrpt_set_stream) and returns nothing.
+    band_view: torch view of rows [y0, y1) of the context's accumulation image.
+    resolve(accum_tensor, out_tensor, stream_handle): Output = rgb / a (hrpt_resolve_device on GPUs).
+    """
+
+    def __init__(self, render_band, band_view, height, width, rank, world, all_gather, resolve, device):
+        import torch
+        self.torch = torch
+        self.render_band, self.band_view, self.all_gather, self.resolve = render_band, band_view, all_gather, resolve
+        self.rank, self.world = rank, world
+        self.y0, self.y1 = band_for_rank(height, world, rank)
+        self.gpu = device.type == "cuda"
+        kw = dict(dtype=torch.float32, device=device)
+        self.staging = [torch.empty((self.y1 - self.y0, width, 4), **kw) for _ in range(2)]
+        self.gathered = [torch.empty((height, width, 4), **kw) for _ in range(2)]
+        self.output = [torch.empty((height, width, 4), **kw) for _ in range(2)]
+        self.frame = 0
+        if self.gpu:
+            self.comm = torch.cuda.Stream(device)
+            self.rendered = [torch.cuda.Event() for _ in range(2)]
+            self.delivered = [torch.cuda.Event() for _ in range(2)]
+
+    def submit(self):
+        """Enqueue one frame; returns the slot (0/1) whose `gathered`/`output` images will hold it."""
+        torch = self.torch
+        s = self.frame & 1
+        if self.gpu:
+            main = torch.cuda.current_stream()
+            if self.frame >= 2:
+                main.wait_event(self.delivered[s])          # slot s is free again once frame-2's gather + resolve are done
+            self.render_band(self.y0, self.y1)
+            self.staging[s].copy_(self.band_view)           # the only payload that crosses xGMI
+            self.rendered[s].record(main)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.rendered[s])
+                self.all_gather(self.gathered[s], self.staging[s])
+                self.resolve(self.gathered[s], self.output[s], self.comm.cuda_stream)
+                self.delivered[s].record(self.comm)
+        else:
+            self.render_band(self.y0, self.y1)
+            self.staging[s].copy_(self.band_view)
+            self.all_gather(self.gathered[s], self.staging[s])
+            self.resolve(self.gathered[s], self.output[s], 0)
+        self.frame += 1
+        return s
+
+    def finish(self):
+        """Make the compute stream wait for every submitted frame (host synchronisation stays with the caller)."""
+        if self.gpu:
+            self.torch.cuda.current_stream().wait_stream(self.comm)

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -48,6 +48,7 @@ lib.hrpt_read_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_read_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_write_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_resolve_output.argtypes = [C.c_void_p]
+lib.hrpt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
@@ -152,6 +153,11 @@ class PathTracerContext:
 
     def resolve_output(self):
         self._check(lib.hrpt_resolve_output(self._h))
+
+    def resolve_device(self, accumulation_ptr, output_ptr, pixel_count, hip_stream=0):
+        """Output = accum.rgb / accum.a over caller-owned device images, asynchronously on `hip_stream` (integer handle)."""
+        self._check(lib.hrpt_resolve_device(self._h, C.c_void_p(int(accumulation_ptr)), C.c_void_p(int(output_ptr)), int(pixel_count),
+                                            C.c_void_p(int(hip_stream))))
 
     def stats(self):
         st = S.Stats()

@@ -268,6 +268,10 @@ int  hrpt_read_output(HrptContext* ctx, float* rgba, size_t bytes);
 int  hrpt_write_accumulation(HrptContext* ctx, const float* rgba, size_t bytes);
 /* Output = accum.rgb / accum.a for every pixel (PathTracer.hlsl:339), e.g. after an all-gather of accumulation tiles. */
 int  hrpt_resolve_output(HrptContext* ctx);
+/* The same resolve over caller-owned DEVICE images (pixelCount float4 each) on the caller's stream: the consumer of a
+ * gathered accumulation image that lives outside the context (pipelined multi-GPU frames, hobbyrenderer_amd/distributed.py).
+ * Asynchronous; stream is a hipStream_t (NULL = the default stream). */
+int  hrpt_resolve_device(HrptContext* ctx, const float* accumulationDevice, float* outputDevice, uint64_t pixelCount, void* stream);
 
 /* ---- HDR post chain: the consumer of the pass -------------------------------------------------
  * HDRRenderer::Render (src/HDRRenderer.cpp:88-224) over Output (u0 = g_RG_HDRColor in path-tracer mode):

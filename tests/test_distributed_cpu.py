@@ -53,6 +53,59 @@ def test_two_rank_band_sharding_matches_single_rank(tmp_path, luts):
     assert np.array_equal(a1.view(np.uint32), ref.view(np.uint32))
 
 
+def _pipelined_worker(rank, world, port, w, h, bounces, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hobbyrenderer_amd import native, scenes
+    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank
+    from oracle.binding import Oracle
+    luts = native.precompute_atmosphere(2)
+    sc, view, pos, _ = scenes.config_cornell(luts, w, h)
+    o = Oracle(sc)
+    acc = np.zeros((h, w, 4), np.float32)
+    out = np.zeros((h, w, 4), np.float32)
+    state = {"first": 0}
+
+    def render_band(y0, y1):       # frame f = accumulation index f alone, restarted from zero (three different frames)
+        acc[y0:y1] = 0.0
+        o.render(scenes.fill_constants(view, pos, sc, state["first"], bounces), acc, out, (0, y0, w, y1), nthreads=2)
+
+    def resolve(a, b, stream):
+        b.copy_(a / a[..., 3:4])
+
+    y0, y1 = band_for_rank(h, world, rank)
+    full = torch.from_numpy(acc)
+    frames = PipelinedFrames(render_band, full[y0:y1], h, w, rank, world, lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"))
+    for f in range(3):
+        state["first"] = f
+        slot = frames.submit()
+        assert slot == (f & 1)
+        np.save(os.path.join(out_dir, f"frame{f}_{rank}.npy"), frames.gathered[slot].numpy().copy())
+    frames.finish()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_frames(tmp_path, luts):
+    """PipelinedFrames bookkeeping (double-buffered staging / gathered images) under gloo, world 2: every frame of every
+    rank equals the single-rank image of that accumulation index."""
+    from hobbyrenderer_amd import scenes
+    from oracle.binding import Oracle
+    w, h, bounces = 48, 28, 3
+    port = 30100 + (os.getpid() % 500)
+    mp.spawn(_pipelined_worker, args=(2, port, w, h, bounces, str(tmp_path)), nprocs=2, join=True)
+    sc, view, pos, _ = scenes.config_cornell(luts, w, h)
+    o = Oracle(sc)
+    for f in range(3):
+        acc = np.zeros((h, w, 4), np.float32); out = np.zeros((h, w, 4), np.float32)
+        o.render(scenes.fill_constants(view, pos, sc, f, bounces), acc, out)
+        for r in range(2):
+            assert np.array_equal(np.load(tmp_path / f"frame{f}_{r}.npy").view(np.uint32), acc.view(np.uint32)), (f, r)
+
+
 def test_band_for_rank():
     from hobbyrenderer_amd.distributed import band_for_rank
     assert [band_for_rank(1080, 8, r) for r in range(8)] == [(135 * r, 135 * (r + 1)) for r in range(8)]

@@ -47,6 +47,32 @@ def test_device_tensor_view_and_rccl_allgather(luts):
         assert (host[..., 3] == 2).all()
         y0, y1 = render_sharded(lambda a, b: None, full, 0, 1, dist.all_gather_into_tensor)
         assert (y0, y1) == (0, 72)
+
+        # pipelined frames: gather + resolve of frame k on a second stream while frame k+1 renders (5 frames, 2 slots)
+        from hobbyrenderer_amd.distributed import PipelinedFrames
+        first = {"i": 0}
+
+        def render_frame(a, b):
+            ctx.render(scenes.fill_constants(view, pos, sc, first["i"], 4), accum_count=1, tile=(0, a, 128, b))
+
+        frames = PipelinedFrames(render_frame, full[0:72], 72, 128, 0, 1, lambda f, b: dist.all_gather_into_tensor(f, b),
+                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), 72 * 128, stream), dev)
+        got = []
+        for f in range(5):
+            first["i"] = f
+            slot = frames.submit()
+            if f >= 3:
+                got.append((f, slot))
+        frames.finish()
+        torch.cuda.synchronize(dev)
+        for f, slot in got:          # the last two frames still sit in their slots
+            ref_ctx = PathTracerContext(0)
+            ref_ctx.upload_scene(sc); ref_ctx.resize(128, 72)
+            ref_ctx.render(scenes.fill_constants(view, pos, sc, 0, 4), accum_count=f + 1)   # frames accumulate progressively: 0..f
+            ra, ro = ref_ctx.read_accumulation(), ref_ctx.read_output()
+            ref_ctx.close()
+            assert np.array_equal(frames.gathered[slot].cpu().numpy().view(np.uint32), ra.view(np.uint32)), f
+            assert np.array_equal(frames.output[slot].cpu().numpy().view(np.uint32), ro.view(np.uint32)), f
         ctx.close()
     finally:
         dist.destroy_process_group()
