@@ -45,6 +45,7 @@ struct WavefrontState {
     // second stream + fork/join events: wf_shadow(b) overlaps wf_extend(b+1) (they share no buffer)
     hipStream_t auxStream = nullptr;
     std::vector<hipEvent_t> forkEvents, joinEvents;
+    uint32_t padLdsBytes = 0;          // experiment: extra dynamic LDS per trace block (lowers occupancy)
     uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
 };

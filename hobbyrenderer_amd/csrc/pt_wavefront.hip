@@ -643,7 +643,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const size_t bvhBytes = (v.width == 2 ? (size_t)scene.nodeCount * 64 : (size_t)scene.node4Count * 128) + (size_t)scene.triCount * 48;
         const size_t stackBytes = (size_t)v.depth * kBlock * 4;
         v.lds = bvhBytes > 0 && stackBytes + extraBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
-        v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0);
+        v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0) + st.padLdsBytes;
         return v;
     };
     const int forced = st.bvhWidth == 2 ? 2 : (st.bvhWidth == 4 ? 4 : 0);

@@ -12,6 +12,9 @@ f32, u32 = np.float32, np.uint32
 VertexQuantized = np.dtype([("m_Pos", f32, 3), ("m_Normal", u32), ("m_Uv", u32), ("m_Tangent", u32)])
 MeshData = np.dtype([("m_LODCount", u32), ("m_IndexOffsets", u32, 8), ("m_IndexCounts", u32, 8),
                      ("m_MeshletOffsets", u32, 8), ("m_MeshletCounts", u32, 8), ("m_LODErrors", f32, 8)])
+Meshlet = np.dtype([("m_CenterRadius", u32, 2), ("m_VertexOffset", u32), ("m_TriangleOffset", u32), ("m_VertexCount", u32),
+                    ("m_TriangleCount", u32), ("m_ConeAxisAndCutoff", u32)])                    # Mesh.sr:27-35, 28 B
+Primitive = np.dtype([("m_VertexOffset", u32), ("m_VertexCount", u32), ("m_MaterialIndex", np.int32), ("m_MeshDataIndex", u32)])  # as serialised, 16 B
 PerInstanceData = np.dtype([("m_World", f32, (4, 4)), ("m_PrevWorld", f32, (4, 4)), ("m_MaterialIndex", u32),
                             ("m_MeshDataIndex", u32), ("m_Radius", f32), ("m_LODIndex", u32), ("m_Center", f32, 3),
                             ("m_FirstGeometryInstanceIndex", u32)])

@@ -80,6 +80,8 @@ public:
     std::vector<uint32_t> m_Indices;                  // backing store of m_IndexBuffer (global vertex indices)
     std::vector<srrhi::PerInstanceData> m_InstanceData;
     std::vector<srrhi::MeshData> m_MeshData;
+    std::vector<srrhi::Meshlet> m_Meshlets;             // carried through the cooked-mesh cache; the path tracer reads LOD-0 indices only
+    std::vector<uint32_t> m_MeshletVertices, m_MeshletTriangles;
     std::vector<srrhi::MaterialConstants> m_MaterialConstants;
     std::vector<srrhi::GPULight> m_GPULights;
     // Bruneton LUTs in the float32 layout of bin/bruneton/*.dat (src/CommonResources.cpp:519-569)

@@ -28,6 +28,7 @@ struct MeshData {                                                               
     uint32_t m_LODCount = 0, m_IndexOffsets[8] = {}, m_IndexCounts[8] = {}, m_MeshletOffsets[8] = {}, m_MeshletCounts[8] = {};
     float m_LODErrors[8] = {};
 };
+struct Meshlet { uint32_t m_CenterRadius[2] = {}, m_VertexOffset = 0, m_TriangleOffset = 0, m_VertexCount = 0, m_TriangleCount = 0, m_ConeAxisAndCutoff = 0; };   // Mesh.sr:27-35
 struct PerInstanceData {                                                                                         // Instance.sr:49-65
     Matrix m_World, m_PrevWorld; uint32_t m_MaterialIndex = 0, m_MeshDataIndex = 0; float m_Radius = 0; uint32_t m_LODIndex = 0;
     Vector3 m_Center; uint32_t m_FirstGeometryInstanceIndex = 0;
