@@ -200,15 +200,14 @@ inline void unpack_tangent(const HrptVertexQuantized& q, float* t)
 
 } // namespace
 
-bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
+bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& error)
 {
-    out = BuiltBvh();
+    triCount = 0;
     if ((!s.vertices && s.vertexCount) || (!s.indices && s.indexCount) || (!s.meshData && s.meshDataCount) || (!s.instances && s.instanceCount) ||
         (!s.materials && s.materialCount) || !s.lights) { error = "null scene array with a non-zero count"; return false; }
     if (s.lightCount == 0) { error = "scene needs at least one light (the reference guarantees a directional light, src/Scene.cpp:635-666)"; return false; }
     for (uint32_t i = 0; i < s.indexCount; ++i)
         if (s.indices[i] >= s.vertexCount) { error = "index buffer references a vertex out of range"; return false; }
-    uint64_t triCount = 0;
     for (uint32_t i = 0; i < s.instanceCount; ++i) {
         const HrptPerInstanceData& in = s.instances[i];
         if (in.m_MeshDataIndex >= s.meshDataCount) { error = "instance m_MeshDataIndex out of range"; return false; }
@@ -219,6 +218,33 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
         triCount += md.m_IndexCounts[0] / 3;
     }
     if (triCount >= (1ull << 29)) { error = "too many triangles"; return false; }
+    return true;
+}
+
+void build_instance_shade(const HrptSceneDesc& s, std::vector<HostInstShade>& out)
+{
+    // per-instance adjugate rows (TransformNormal, Common.hlsli:33-47)
+    out.resize(s.instanceCount);
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const float* M = s.instances[i].m_World;
+        const float r0[3] = { M[0], M[1], M[2] }, r1[3] = { M[4], M[5], M[6] }, r2[3] = { M[8], M[9], M[10] };
+        HostInstShade& is = out[i];
+        cross3(r1, r2, is.adj0); cross3(r2, r0, is.adj1); cross3(r0, r1, is.adj2);
+        is.adj0[3] = is.adj1[3] = is.adj2[3] = 0.0f;
+    }
+}
+
+bool scene_needs_tangents(const HrptSceneDesc& s)
+{
+    for (uint32_t m = 0; m < s.materialCount; ++m) if (s.materials[m].m_TextureFlags & HRPT_TEXFLAG_NORMAL) return true;
+    return false;
+}
+
+bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
+{
+    out = BuiltBvh();
+    uint64_t triCount = 0;
+    if (!validate_scene(s, triCount, error)) return false;
 
     std::vector<HostTri> tris; tris.reserve((size_t)triCount);
     for (uint32_t i = 0; i < s.instanceCount; ++i) {
@@ -235,15 +261,7 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
             tris.push_back(t);
         }
     }
-    // per-instance adjugate rows (TransformNormal, Common.hlsli:33-47)
-    out.instShade.resize(s.instanceCount);
-    for (uint32_t i = 0; i < s.instanceCount; ++i) {
-        const float* M = s.instances[i].m_World;
-        const float r0[3] = { M[0], M[1], M[2] }, r1[3] = { M[4], M[5], M[6] }, r2[3] = { M[8], M[9], M[10] };
-        HostInstShade& is = out.instShade[i];
-        cross3(r1, r2, is.adj0); cross3(r2, r0, is.adj1); cross3(r0, r1, is.adj2);
-        is.adj0[3] = is.adj1[3] = is.adj2[3] = 0.0f;
-    }
+    build_instance_shade(s, out.instShade);
     if (tris.empty()) return true;
 
     Builder b; b.src = &tris; b.out = &out;
@@ -266,8 +284,7 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     else { out.nodes4.reserve(out.nodes.size() / 2 + 1); collapse4(out.nodes, 0, out.nodes4, 0, out.maxDepth4); }
 
     // shading attributes in leaf order
-    bool needTangents = false;
-    for (uint32_t m = 0; m < s.materialCount; ++m) if (s.materials[m].m_TextureFlags & HRPT_TEXFLAG_NORMAL) needTangents = true;
+    const bool needTangents = scene_needs_tangents(s);
     out.attrs.resize(out.tris.size());
     if (needTangents) out.tangents.resize(out.tris.size());
     for (size_t k = 0; k < out.tris.size(); ++k) {

@@ -70,7 +70,11 @@ struct BuiltBvh {
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr uint32_t kTraversalStackDepth = 32;   // the builder guarantees depth < this
 
-// Validates every index of the scene description (returns false + message) and builds the BVH.
+// Validates every index / range of the scene description (false + message); triCount = world triangles over all instances.
+bool validate_scene(const HrptSceneDesc& scene, uint64_t& triCount, std::string& error);
+void build_instance_shade(const HrptSceneDesc& scene, std::vector<HostInstShade>& out);
+bool scene_needs_tangents(const HrptSceneDesc& scene);
+// validate_scene + host build (binned SAH).
 bool build_scene_bvh(const HrptSceneDesc& scene, BuiltBvh& out, std::string& error);
 
 } // namespace hrt

@@ -1,0 +1,475 @@
+// bvh_build_gpu.hip -- the acceleration structure of Scene::BuildAccelerationStructures (/root/reference/src/Scene.cpp:67-214)
+// built ON the GPU: world-space triangle setup, 63-bit Morton codes, radix sort (rocPRIM), Karras-2012
+// radix-tree hierarchy, bottom-up bounds, leaf formation (<= 4 triangles), BVH2 emission, 4-wide collapse and the per-triangle
+// shading-attribute records -- the same outputs as the host builder (bvh_build.cpp), in device memory, without the host ever
+// touching a triangle. The reference hands this job to the D3D12 driver (BLAS/TLAS build on the graphics queue); real-time modes
+// rebuild the TLAS every frame (src/CommonRenderers.cpp:234-246), which is what a GPU build is for.
+//
+// Radiance does not depend on which builder ran: the hit definition of pt_device.h is BVH-independent (closest = min (t, inst, prim),
+// candidates revisited through exclusive lower keys), boxes are padded conservatively with the host builder's rule, and the world
+// transform / attribute unpacking use the same expression order with -ffp-contract=off.
+#include "bvh_build_gpu.h"
+
+#include <cstring>
+using std::memset;   // rocprim/iterator/texture_cache_iterator.hpp calls an unqualified memset
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace hrt {
+namespace {
+
+constexpr int kB = 256;
+constexpr uint32_t kLeafBit = 0x80000000u;   // radix-tree child reference: leaf (sorted primitive index) when set
+
+struct InstRec {            // per instance, host-prepared
+    float world[16];
+    uint32_t indexOffset, triBase, material, opaque;
+};
+
+struct BuildBuffers {
+    // inputs
+    const HrptVertexQuantized* vertices; const uint32_t* indices; const InstRec* inst; uint32_t instCount; uint32_t triCount;
+    // per unsorted triangle
+    GpuTri* triU; float4* boxMinU; float4* boxMaxU;
+    uint64_t* keyA; uint64_t* keyB; uint32_t* valA; uint32_t* valB;
+    uint32_t* sceneBounds;      // 6 ordered-uint floats: centroid min xyz, max xyz
+    uint32_t* flags;            // [0] non-finite vertex seen, [1] max depth of the kept BVH2, [2] kept inner node count (host reads)
+    // radix tree (n-1 internal nodes)
+    uint32_t* childL; uint32_t* childR; uint32_t* rangeFirst; uint32_t* rangeLast; uint32_t* parentOfInternal; uint32_t* parentOfLeaf;
+    uint32_t* visit; float4* nodeMin; float4* nodeMax;
+    uint32_t* keep; uint32_t* newIndex;         // kept (range > 4) internal nodes -> dense BVH2 index
+    uint32_t* keptParent; uint32_t* depth;      // per dense BVH2 node
+    uint32_t* even; uint32_t* index4;           // per dense BVH2 node: even depth -> BVH4 node index
+    // outputs
+    GpuNode* nodes; GpuNode4* nodes4; GpuTri* tris; GpuTriAttr* attrs; GpuTriTangent* tangents;
+};
+
+__device__ __forceinline__ uint32_t ordered(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__device__ __forceinline__ void xform(const float* p, const float* M, float* o)
+{   // mul(float4(p,1), M).xyz, left to right, no FMA (bvh_build.cpp transform_point)
+    o[0] = ((p[0] * M[0] + p[1] * M[4]) + p[2] * M[8]) + M[12];
+    o[1] = ((p[0] * M[1] + p[1] * M[5]) + p[2] * M[9]) + M[13];
+    o[2] = ((p[0] * M[2] + p[1] * M[6]) + p[2] * M[10]) + M[14];
+}
+
+__device__ __forceinline__ uint32_t find_instance(const InstRec* inst, uint32_t n, uint32_t g)
+{   // last instance whose triBase <= g (instances with zero triangles share a base with their successor and are skipped)
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (inst[mid].triBase <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ---- 1. world-space triangles, padded boxes, centroid bounds
+__global__ __launch_bounds__(kB) void k_setup(BuildBuffers b)
+{
+    uint32_t g = blockIdx.x * kB + threadIdx.x;
+    float cmin[3] = { 3e38f, 3e38f, 3e38f }, cmax[3] = { -3e38f, -3e38f, -3e38f };
+    if (g < b.triCount) {
+        uint32_t i = find_instance(b.inst, b.instCount, g);
+        const InstRec& in = b.inst[i];
+        uint32_t p = g - in.triBase;
+        const uint32_t* ix = b.indices + in.indexOffset + 3 * (size_t)p;
+        float v[3][3];
+        for (int k = 0; k < 3; ++k) xform(b.vertices[ix[k]].m_Pos, in.world, v[k]);
+        GpuTri t;
+        for (int k = 0; k < 3; ++k) { t.p0[k] = v[0][k]; t.p1[k] = v[1][k]; t.p2[k] = v[2][k]; }
+        t.inst = i; t.prim = p; t.flags = in.opaque;
+        b.triU[g] = t;
+        float mn[3], mx[3], c[3]; bool bad = false;
+        for (int k = 0; k < 3; ++k) {
+            float lo = fminf(v[0][k], fminf(v[1][k], v[2][k])), hi = fmaxf(v[0][k], fmaxf(v[1][k], v[2][k]));
+            bad = bad || !(v[0][k] == v[0][k]) || !(v[1][k] == v[1][k]) || !(v[2][k] == v[2][k]) || isinf(lo) || isinf(hi);
+            float pad = 1e-5f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;      // the host builder's conservative padding
+            mn[k] = lo - pad; mx[k] = hi + pad; c[k] = 0.5f * lo + 0.5f * hi;
+            cmin[k] = c[k]; cmax[k] = c[k];
+        }
+        if (bad) atomicOr(&b.flags[0], 1u);
+        b.boxMinU[g] = make_float4(mn[0], mn[1], mn[2], c[0]);
+        b.boxMaxU[g] = make_float4(mx[0], mx[1], mx[2], c[1]);
+        b.keyA[g] = (uint64_t)__float_as_uint(c[2]);          // parked: centroid z until k_morton replaces it
+    }
+    // block reduction of the centroid bounds, one atomic pair per axis per block
+    __shared__ float smin[3][kB / 64], smax[3][kB / 64];
+    for (int k = 0; k < 3; ++k) {
+        float lo = cmin[k], hi = cmax[k];
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+        if ((threadIdx.x & 63) == 0) { smin[k][threadIdx.x >> 6] = lo; smax[k][threadIdx.x >> 6] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float lo = smin[threadIdx.x][0], hi = smax[threadIdx.x][0];
+        for (int w = 1; w < kB / 64; ++w) { lo = fminf(lo, smin[threadIdx.x][w]); hi = fmaxf(hi, smax[threadIdx.x][w]); }
+        if (lo <= hi) { atomicMin(&b.sceneBounds[threadIdx.x], ordered(lo)); atomicMax(&b.sceneBounds[3 + threadIdx.x], ordered(hi)); }
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t x)
+{   // 21 bits -> every third bit of 63
+    uint64_t v = x & 0x1fffffu;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+// ---- 2. 63-bit Morton code of the centroid inside the centroid bounds
+__global__ __launch_bounds__(kB) void k_morton(BuildBuffers b)
+{
+    uint32_t g = blockIdx.x * kB + threadIdx.x;
+    if (g >= b.triCount) return;
+    float c[3] = { b.boxMinU[g].w, b.boxMaxU[g].w, __uint_as_float((uint32_t)b.keyA[g]) };
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float lo = unordered(b.sceneBounds[k]), hi = unordered(b.sceneBounds[3 + k]);
+        float ext = hi - lo;
+        float t = ext > 0.0f ? (c[k] - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        uint32_t v = (uint32_t)(t * 2097151.0f);
+        q[k] = v > 2097151u ? 2097151u : v;
+    }
+    b.keyA[g] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    b.valA[g] = g;
+}
+
+// ---- 3. Karras 2012: one thread per internal node of the binary radix tree over the sorted keys (ties broken by position)
+// `shift` drops the low Morton bits: keys equal after the shift are split by position, i.e. by balanced halving of a run that is
+// still in full-Morton (spatial) order -- this bounds the depth by (63 - shift) + log2(longest run).
+__device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j, int shift)
+{
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i] >> shift, c = keys[j] >> shift;
+    if (a == c) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ c));
+}
+__global__ __launch_bounds__(kB) void k_hierarchy(BuildBuffers b, int shift)
+{
+    const int n = (int)b.triCount;
+    int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    const uint64_t* keys = b.keyB;
+    int d = (delta(keys, n, i, i + 1, shift) - delta(keys, n, i, i - 1, shift)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d, shift);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d, shift) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (delta(keys, n, i, i + (l + t) * d, shift) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j, shift);
+    int s = 0;
+    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
+        if (delta(keys, n, i, i + (s + t) * d, shift) > dnode) s += t;
+        if (t == 1) break;
+    }
+    int gamma = i + s * d + (d < 0 ? -1 : 0);
+    int first = i < j ? i : j, last = i < j ? j : i;
+    uint32_t cl = (first == gamma) ? ((uint32_t)gamma | kLeafBit) : (uint32_t)gamma;
+    uint32_t cr = (last == gamma + 1) ? ((uint32_t)(gamma + 1) | kLeafBit) : (uint32_t)(gamma + 1);
+    b.childL[i] = cl; b.childR[i] = cr; b.rangeFirst[i] = (uint32_t)first; b.rangeLast[i] = (uint32_t)last;
+    if (cl & kLeafBit) b.parentOfLeaf[gamma] = (uint32_t)i; else b.parentOfInternal[gamma] = (uint32_t)i;
+    if (cr & kLeafBit) b.parentOfLeaf[gamma + 1] = (uint32_t)i; else b.parentOfInternal[gamma + 1] = (uint32_t)i;
+    if (i == 0) b.parentOfInternal[0] = 0xFFFFFFFFu;
+}
+
+// ---- 4. bottom-up bounds: the second thread to reach a node merges its children's boxes
+__global__ __launch_bounds__(kB) void k_fit(BuildBuffers b)
+{
+    uint32_t leaf = blockIdx.x * kB + threadIdx.x;
+    if (leaf >= b.triCount) return;
+    uint32_t node = b.parentOfLeaf[leaf];
+    while (node != 0xFFFFFFFFu) {
+        if (atomicAdd(&b.visit[node], 1u) == 0u) return;       // first arrival: the sibling subtree is not finished yet
+        __threadfence();
+        float4 mn[2], mx[2];
+        uint32_t ch[2] = { b.childL[node], b.childR[node] };
+        for (int k = 0; k < 2; ++k) {
+            if (ch[k] & kLeafBit) { uint32_t g = b.valB[ch[k] & ~kLeafBit]; mn[k] = b.boxMinU[g]; mx[k] = b.boxMaxU[g]; }
+            else { mn[k] = b.nodeMin[ch[k]]; mx[k] = b.nodeMax[ch[k]]; }
+        }
+        b.nodeMin[node] = make_float4(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z), 0.0f);
+        b.nodeMax[node] = make_float4(fmaxf(mx[0].x, mx[1].x), fmaxf(mx[0].y, mx[1].y), fmaxf(mx[0].z, mx[1].z), 0.0f);
+        __threadfence();
+        node = b.parentOfInternal[node];
+    }
+}
+
+// ---- 5. leaves of up to 4 triangles: an internal node stays inner iff its range holds more than kMaxLeafTris primitives
+__global__ __launch_bounds__(kB) void k_classify(BuildBuffers b)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i + 1 >= b.triCount) return;
+    b.keep[i] = (b.rangeLast[i] - b.rangeFirst[i] + 1u > 4u) ? 1u : 0u;
+}
+
+__device__ __forceinline__ int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1u)); }
+
+// child reference + box in the emitted BVH2
+__device__ __forceinline__ void child_ref(const BuildBuffers& b, uint32_t ch, int32_t& ref, float4& mn, float4& mx)
+{
+    if (ch & kLeafBit) {
+        uint32_t k = ch & ~kLeafBit, g = b.valB[k];
+        ref = encode_leaf(k, 1u); mn = b.boxMinU[g]; mx = b.boxMaxU[g];
+    } else {
+        mn = b.nodeMin[ch]; mx = b.nodeMax[ch];
+        ref = b.keep[ch] ? (int32_t)b.newIndex[ch] : encode_leaf(b.rangeFirst[ch], b.rangeLast[ch] - b.rangeFirst[ch] + 1u);
+    }
+}
+
+// ---- 6. dense BVH2 in the traversal layout (child boxes live in the parent)
+__global__ __launch_bounds__(kB) void k_emit2(BuildBuffers b)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i + 1 >= b.triCount || !b.keep[i]) return;
+    int32_t lr, rr; float4 lmn, lmx, rmn, rmx;
+    child_ref(b, b.childL[i], lr, lmn, lmx);
+    child_ref(b, b.childR[i], rr, rmn, rmx);
+    uint32_t me = b.newIndex[i];
+    GpuNode n;
+    n.lmin[0] = lmn.x; n.lmin[1] = lmn.y; n.lmin[2] = lmn.z; n.left = lr;
+    n.lmax[0] = lmx.x; n.lmax[1] = lmx.y; n.lmax[2] = lmx.z; n.right = rr;
+    n.rmin[0] = rmn.x; n.rmin[1] = rmn.y; n.rmin[2] = rmn.z; n.pad0 = 0;
+    n.rmax[0] = rmx.x; n.rmax[1] = rmx.y; n.rmax[2] = rmx.z; n.pad1 = 0;
+    b.nodes[me] = n;
+    if (lr >= 0) b.keptParent[lr] = me;
+    if (rr >= 0) b.keptParent[rr] = me;
+    if (i == 0) b.keptParent[0] = 0xFFFFFFFFu;
+}
+
+// ---- 7. depth of every dense node (walk to the root), max depth, even-depth flags
+__global__ __launch_bounds__(kB) void k_depth(BuildBuffers b, uint32_t nodeCount)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    uint32_t d = 0;
+    if (k < nodeCount) {
+        for (uint32_t p = b.keptParent[k]; p != 0xFFFFFFFFu; p = b.keptParent[p]) ++d;
+        b.depth[k] = d; b.even[k] = (d & 1u) ? 0u : 1u;
+    }
+    uint32_t m = d;
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&b.flags[1], m);
+}
+
+// ---- 8. 4-wide collapse: every even-depth node absorbs its inner children (two BVH2 levels per BVH4 level)
+__global__ __launch_bounds__(kB) void k_emit4(BuildBuffers b, uint32_t nodeCount)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= nodeCount || !b.even[k]) return;
+    int32_t ref[4]; float mn[4][3], mx[4][3]; int cnt = 0;
+    auto push = [&](int32_t r, float4 a, float4 c) { ref[cnt] = r; mn[cnt][0] = a.x; mn[cnt][1] = a.y; mn[cnt][2] = a.z; mx[cnt][0] = c.x; mx[cnt][1] = c.y; mx[cnt][2] = c.z; ++cnt; };
+    auto f4 = [](const float* p) { return make_float4(p[0], p[1], p[2], 0.0f); };
+    GpuNode n = b.nodes[k];
+    int32_t c2[2] = { n.left, n.right };
+    float4 bmn[2] = { f4(n.lmin), f4(n.rmin) }, bmx[2] = { f4(n.lmax), f4(n.rmax) };
+    for (int s = 0; s < 2; ++s) {
+        if (c2[s] >= 0) {
+            GpuNode m = b.nodes[c2[s]];
+            push(m.left, f4(m.lmin), f4(m.lmax));
+            push(m.right, f4(m.rmin), f4(m.rmax));
+        } else push(c2[s], bmn[s], bmx[s]);
+    }
+    GpuNode4 o;
+    float* px[6] = { &o.minx.x, &o.miny.x, &o.minz.x, &o.maxx.x, &o.maxy.x, &o.maxz.x };
+    int32_t* pc = &o.child.x;
+    for (int s = 0; s < 4; ++s) {
+        bool used = s < cnt;
+        for (int a = 0; a < 3; ++a) { px[a][s] = used ? mn[s][a] : 1e30f; px[3 + a][s] = used ? mx[s][a] : 1e30f; }   // far degenerate box = never hit
+        pc[s] = used ? (ref[s] >= 0 ? (int32_t)b.index4[ref[s]] : ref[s]) : 0x7fffffff;
+    }
+    o.pad = make_uint4(0, 0, 0, 0);
+    b.nodes4[b.index4[k]] = o;
+}
+
+// ---- 9. triangles and shading attributes in leaf (sorted) order
+__device__ __forceinline__ float half_bits(uint32_t h)
+{   // f16tof32 (include/hobbyrt/detmath.h), exact
+    uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) { if (m == 0) return __uint_as_float(s); float f = (float)m * __uint_as_float(0x33800000u); return s ? -f : f; }
+    if (e == 31) return __uint_as_float(s | 0x7f800000u | (m << 13));
+    return __uint_as_float(s | ((e + 112u) << 23) | (m << 13));
+}
+__device__ __forceinline__ void unpack_normal(const HrptVertexQuantized& q, float* n)
+{   // UnpackVertex, MeshCommon.hlsli:9-22
+    n[0] = (float)(q.m_Normal & 1023u) / 511.0f - 1.0f;
+    n[1] = (float)((q.m_Normal >> 10) & 1023u) / 511.0f - 1.0f;
+    n[2] = (float)((q.m_Normal >> 20) & 1023u) / 511.0f - 1.0f;
+}
+__device__ __forceinline__ float4 unpack_tangent(const HrptVertexQuantized& q)
+{   // DecodeOct, Common.hlsli:174-181
+    float ex = (float)(q.m_Tangent & 255u) / 127.0f - 1.0f, ey = (float)((q.m_Tangent >> 8) & 255u) / 127.0f - 1.0f;
+    float v[3] = { ex, ey, (1.0f - fabsf(ex)) - fabsf(ey) };
+    float neg = -v[2];
+    float tt = (neg >= 0.0f) ? neg : 0.0f;
+    v[0] += (v[0] >= 0.0f) ? -tt : tt;
+    v[1] += (v[1] >= 0.0f) ? -tt : tt;
+    float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    return make_float4(v[0] * inv, v[1] * inv, v[2] * inv, (q.m_Normal & (1u << 30)) != 0 ? -1.0f : 1.0f);
+}
+__global__ __launch_bounds__(kB) void k_attrs(BuildBuffers b)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= b.triCount) return;
+    uint32_t g = b.valB[k];
+    GpuTri t = b.triU[g];
+    b.tris[k] = t;
+    uint32_t i = t.inst, p = t.prim;
+    const InstRec& in = b.inst[i];
+    const uint32_t* ix = b.indices + in.indexOffset + 3 * (size_t)p;
+    HrptVertexQuantized q0 = b.vertices[ix[0]], q1 = b.vertices[ix[1]], q2 = b.vertices[ix[2]];
+    float n0[3], n1[3], n2[3];
+    unpack_normal(q0, n0); unpack_normal(q1, n1); unpack_normal(q2, n2);
+    GpuTriAttr a;
+    a.a = make_float4(n0[0], n0[1], n0[2], n1[0]);
+    a.b = make_float4(n1[1], n1[2], n2[0], n2[1]);
+    a.c = make_float4(n2[2], half_bits(q0.m_Uv & 0xFFFFu), half_bits(q0.m_Uv >> 16), half_bits(q1.m_Uv & 0xFFFFu));
+    a.d = make_float4(half_bits(q1.m_Uv >> 16), half_bits(q2.m_Uv & 0xFFFFu), half_bits(q2.m_Uv >> 16), __uint_as_float(in.material));
+    a.e = make_float4(__uint_as_float(i), __uint_as_float(p), 0.0f, 0.0f);
+    b.attrs[k] = a;
+    if (b.tangents) { GpuTriTangent tg; tg.t0 = unpack_tangent(q0); tg.t1 = unpack_tangent(q1); tg.t2 = unpack_tangent(q2); b.tangents[k] = tg; }
+}
+
+__global__ void k_init(uint32_t* sceneBounds, uint32_t* flags)
+{
+    if (threadIdx.x < 3) { sceneBounds[threadIdx.x] = 0xFFFFFFFFu; sceneBounds[3 + threadIdx.x] = 0u; }
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+}
+
+struct Arena {          // one temporary allocation carved into aligned pieces
+    char* base = nullptr; size_t off = 0, cap = 0;
+    template <class T> T* take(size_t n) { size_t o = off; off += (n * sizeof(T) + 255) & ~(size_t)255; return base ? reinterpret_cast<T*>(base + o) : nullptr; }
+};
+
+} // namespace
+
+hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32_t maxStackDepth, const std::function<void*(size_t)>& sceneAlloc,
+                               hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    out = GpuBuiltBvh();
+    hipError_t e;
+    // instance table + triangle prefix (host, O(instances))
+    std::vector<InstRec> inst(s.instanceCount);
+    uint64_t T = 0;
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const HrptPerInstanceData& in = s.instances[i];
+        const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
+        std::memcpy(inst[i].world, in.m_World, sizeof inst[i].world);
+        inst[i].indexOffset = md.m_IndexOffsets[0]; inst[i].triBase = (uint32_t)T; inst[i].material = in.m_MaterialIndex;
+        inst[i].opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+        T += md.m_IndexCounts[0] / 3;
+    }
+    if (T < 8 || T >= (1ull << 29)) { error = "triangle count outside the GPU builder's range"; return hipErrorInvalidValue; }
+    const uint32_t n = (uint32_t)T;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+    auto cleanupEvents = [&]() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); };
+
+    // rocPRIM scratch sizes
+    size_t sortBytes = 0, scanBytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sortBytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, stream);
+    (void)rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), stream);
+
+    BuildBuffers b{};
+    Arena A;
+    void* prim = nullptr; void* scratch = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {      // pass 0 sizes the arena, pass 1 hands out pointers
+        A.off = 0;
+        b.triU = A.take<GpuTri>(n); b.boxMinU = A.take<float4>(n); b.boxMaxU = A.take<float4>(n);
+        b.keyA = A.take<uint64_t>(n); b.keyB = A.take<uint64_t>(n); b.valA = A.take<uint32_t>(n); b.valB = A.take<uint32_t>(n);
+        b.sceneBounds = A.take<uint32_t>(8); b.flags = A.take<uint32_t>(8);
+        b.childL = A.take<uint32_t>(n); b.childR = A.take<uint32_t>(n); b.rangeFirst = A.take<uint32_t>(n); b.rangeLast = A.take<uint32_t>(n);
+        b.parentOfInternal = A.take<uint32_t>(n); b.parentOfLeaf = A.take<uint32_t>(n); b.visit = A.take<uint32_t>(n);
+        b.nodeMin = A.take<float4>(n); b.nodeMax = A.take<float4>(n);
+        b.keep = A.take<uint32_t>(n); b.newIndex = A.take<uint32_t>(n); b.keptParent = A.take<uint32_t>(n); b.depth = A.take<uint32_t>(n);
+        b.even = A.take<uint32_t>(n); b.index4 = A.take<uint32_t>(n);
+        b.nodes = A.take<GpuNode>(n);            // staging: the dense count is known only after the scan
+        b.nodes4 = A.take<GpuNode4>(n / 2 + 1);
+        prim = A.take<char>(std::max(sortBytes, scanBytes));
+        char* vtx = A.take<char>((size_t)s.vertexCount * sizeof(HrptVertexQuantized));
+        char* idx = A.take<char>((size_t)s.indexCount * 4);
+        char* ins = A.take<char>(inst.size() * sizeof(InstRec));
+        b.vertices = reinterpret_cast<const HrptVertexQuantized*>(vtx); b.indices = reinterpret_cast<const uint32_t*>(idx); b.inst = reinterpret_cast<const InstRec*>(ins);
+        if (pass == 0) {
+            if ((e = hipMalloc(&scratch, A.off)) != hipSuccess) { error = "hipMalloc(GPU BVH build scratch)"; cleanupEvents(); return e; }
+            A.base = static_cast<char*>(scratch); A.cap = A.off;
+        }
+    }
+    auto fail = [&](hipError_t err, const char* what) { error = what; (void)hipStreamSynchronize(stream); (void)hipFree(scratch); cleanupEvents(); return err; };
+    b.instCount = s.instanceCount; b.triCount = n;
+    // outputs that live as long as the scene
+    b.tris = static_cast<GpuTri*>(sceneAlloc((size_t)n * sizeof(GpuTri)));
+    b.attrs = static_cast<GpuTriAttr*>(sceneAlloc((size_t)n * sizeof(GpuTriAttr)));
+    b.tangents = needTangents ? static_cast<GpuTriTangent*>(sceneAlloc((size_t)n * sizeof(GpuTriTangent))) : nullptr;
+    if (!b.tris || !b.attrs || (needTangents && !b.tangents)) return fail(hipErrorOutOfMemory, "hipMalloc(GPU BVH outputs)");
+
+    if ((e = hipMemcpyAsync(const_cast<HrptVertexQuantized*>(b.vertices), s.vertices, (size_t)s.vertexCount * sizeof(HrptVertexQuantized), hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(const_cast<uint32_t*>(b.indices), s.indices, (size_t)s.indexCount * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), inst.data(), inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
+        return fail(e, "hipMemcpyAsync(GPU BVH inputs)");
+    (void)hipEventRecord(ev0, stream);
+
+    const dim3 gT((n + kB - 1) / kB), blk(kB);
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, b.sceneBounds, b.flags);
+    hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
+    hipLaunchKernelGGL(k_morton, gT, blk, 0, stream, b);
+    if ((e = rocprim::radix_sort_pairs(prim, sortBytes, b.keyA, b.keyB, b.valA, b.valB, n, 0, 63, stream)) != hipSuccess) return fail(e, "rocprim::radix_sort_pairs");
+    // Hierarchy with the full 63-bit codes first; when the tree is deeper than the traversal stacks allow, drop low Morton bits
+    // (no re-sort: the order stays the full-code order) until it fits.
+    uint32_t nodeCount = 0, maxDepthSeen = 0; int usedBits = 0;
+    const int bitBudgets[] = { 63, 48, 39, 30, 21, 12, 0 };
+    for (int budget : bitBudgets) {
+        const int shift = 63 - budget;
+        (void)hipMemsetAsync(b.visit, 0, (size_t)n * 4, stream);
+        (void)hipMemsetAsync(b.flags + 1, 0, 4, stream);
+        hipLaunchKernelGGL(k_hierarchy, gT, blk, 0, stream, b, shift);
+        hipLaunchKernelGGL(k_fit, gT, blk, 0, stream, b);
+        hipLaunchKernelGGL(k_classify, gT, blk, 0, stream, b);
+        if ((e = rocprim::exclusive_scan(prim, scanBytes, b.keep, b.newIndex, 0u, n - 1, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(keep)");
+        hipLaunchKernelGGL(k_emit2, gT, blk, 0, stream, b);
+        // dense node count = newIndex[n-2] + keep[n-2]
+        uint32_t tail[2] = { 0, 0 };
+        if ((e = hipMemcpyAsync(&tail[0], b.newIndex + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(&tail[1], b.keep + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (hierarchy)");
+        nodeCount = tail[0] + tail[1];
+        if (nodeCount == 0) return fail(hipErrorUnknown, "GPU BVH build produced no inner node");
+        hipLaunchKernelGGL(k_depth, dim3((nodeCount + kB - 1) / kB), blk, 0, stream, b, nodeCount);
+        uint32_t d = 0;
+        if ((e = hipMemcpyAsync(&d, b.flags + 1, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess || (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (depth)");
+        maxDepthSeen = d; usedBits = budget;
+        if (d + 2 <= maxStackDepth) break;
+    }
+    const dim3 gN((nodeCount + kB - 1) / kB);
+    if ((e = rocprim::exclusive_scan(prim, scanBytes, b.even, b.index4, 0u, nodeCount, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(even)");
+    hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount);
+    hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
+    uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 };
+    if ((e = hipMemcpyAsync(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&tail4[0], b.index4 + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&tail4[1], b.even + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (emit)");
+    if (flags[0]) return fail(hipErrorInvalidValue, "non-finite vertex position");
+    const uint32_t node4Count = tail4[0] + tail4[1];
+    // compact copies of the node arrays into scene-lifetime allocations
+    GpuNode* nodes = static_cast<GpuNode*>(sceneAlloc((size_t)nodeCount * sizeof(GpuNode)));
+    GpuNode4* nodes4 = static_cast<GpuNode4*>(sceneAlloc((size_t)node4Count * sizeof(GpuNode4)));
+    if (!nodes || !nodes4) return fail(hipErrorOutOfMemory, "hipMalloc(GPU BVH nodes)");
+    if ((e = hipMemcpyAsync(nodes, b.nodes, (size_t)nodeCount * sizeof(GpuNode), hipMemcpyDeviceToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(nodes4, b.nodes4, (size_t)node4Count * sizeof(GpuNode4), hipMemcpyDeviceToDevice, stream)) != hipSuccess) return fail(e, "hipMemcpyAsync(GPU BVH nodes)");
+    (void)hipEventRecord(ev1, stream);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (finish)");
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipFree(scratch); cleanupEvents();
+
+    out.nodes = nodes; out.nodeCount = nodeCount; out.nodes4 = nodes4; out.node4Count = node4Count;
+    out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n;
+    out.maxDepth = maxDepthSeen; out.maxDepth4 = maxDepthSeen / 2; out.mortonBits = (uint32_t)usedBits; out.deviceMs = ms;
+    return hipSuccess;
+}
+
+} // namespace hrt

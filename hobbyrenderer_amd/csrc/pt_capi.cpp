@@ -3,6 +3,7 @@
 // PathTracerRenderer::Render fills them (/root/reference/src/PathTracerRenderer.cpp:58-75), launches.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +13,7 @@
 
 #include "../../include/hobbyrt_pt.h"
 #include "bvh_build.h"
+#include "bvh_build_gpu.h"
 #include "pt_device.h"
 #include "pt_kernels.h"
 #include "pt_wavefront.h"
@@ -37,6 +39,8 @@ struct HrptContext {
     bool timed = false;
     WavefrontState wf;
     SceneTraits traits;
+    int bvhBuilder = HRPT_BVH_BUILDER_HOST_SAH;   // hrpt_set_bvh_builder
+    HrptBuildInfo buildInfo{};
 };
 
 static std::mutex g_errMutex;
@@ -121,6 +125,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "gpu") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : HRPT_BVH_BUILDER_HOST_SAH;
     if (const char* e = getenv("HRPT_WF_PAD_LDS")) c->wf.padLdsBytes = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
     *out = c;
@@ -162,33 +167,75 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     if (!s->brunetonTransmittance || !s->brunetonScattering) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: Bruneton LUTs missing");
     if (s->textureCount && !s->textures) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: null texture table");
     HIP_TRY(c, hipSetDevice(c->device));
-    BuiltBvh bvh; std::string berr;
-    if (!build_scene_bvh(*s, bvh, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
+    std::string berr;
+    uint64_t sceneTris = 0;
+    if (!validate_scene(*s, sceneTris, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    c->buildInfo = HrptBuildInfo{};
+    c->buildInfo.requestedBuilder = (uint32_t)c->bvhBuilder;
 
     SceneView v{};
     int r;
-    const HostNode* dn; const HostTri* dt;
-    if ((r = upload(c, bvh.nodes.data(), bvh.nodes.size(), &dn)) != HRPT_OK) return r;
-    if ((r = upload(c, bvh.tris.data(), bvh.tris.size(), &dt)) != HRPT_OK) return r;
-    v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
-    v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
-    v.rootLeaf = bvh.rootLeaf;
-    const HostNode4* dn4;
-    if ((r = upload(c, bvh.nodes4.data(), bvh.nodes4.size(), &dn4)) != HRPT_OK) return r;
-    v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)bvh.nodes4.size();
-    // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
-    // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
-    const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
-    if ((r = upload(c, bvh.attrs.data(), bvh.attrs.size(), &da)) != HRPT_OK) return r;
-    if ((r = upload(c, bvh.instShade.data(), bvh.instShade.size(), &dis)) != HRPT_OK) return r;
-    v.attrs = reinterpret_cast<const GpuTriAttr*>(da); v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
-    v.tangents = nullptr;
-    if (!bvh.tangents.empty()) {
-        if ((r = upload(c, bvh.tangents.data(), bvh.tangents.size(), &dtg)) != HRPT_OK) return r;
-        v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
+    uint32_t maxDepth = 0, maxDepth4 = 0;
+    bool built = false;
+    if (c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH && sceneTris >= 8) {
+        // the whole build runs on the device; only the per-instance adjugate rows (O(instances)) are prepared on the host
+        GpuBuiltBvh g; std::string gerr;
+        size_t mark = c->allocations.size();
+        auto sceneAlloc = [c](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; c->allocations.push_back(p); return p; };
+        hipError_t ge = build_scene_bvh_gpu(*s, scene_needs_tangents(*s), kTraversalStackDepth, sceneAlloc, c->stream, g, gerr);
+        if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
+            v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
+            v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
+            maxDepth = g.maxDepth; maxDepth4 = g.maxDepth4; built = true;
+            c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits;
+        } else {
+            // too deep for the traversal stacks (or a device error): drop what was allocated and build on the host instead
+            for (size_t i = mark; i < c->allocations.size(); ++i) (void)hipFree(c->allocations[i]);
+            c->allocations.resize(mark);
+            if (ge == hipErrorInvalidValue && gerr == "non-finite vertex position") return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + gerr);
+            if (ge == hipErrorOutOfMemory) return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_upload_scene: " + gerr);
+        }
+        if (built) {
+            std::vector<HostInstShade> shade; build_instance_shade(*s, shade);
+            const HostInstShade* dis;
+            if ((r = upload(c, shade.data(), shade.size(), &dis)) != HRPT_OK) return r;
+            v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
     }
+    if (!built) {
+        BuiltBvh bvh;
+        if (!build_scene_bvh(*s, bvh, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
+        const HostNode* dn; const HostTri* dt;
+        if ((r = upload(c, bvh.nodes.data(), bvh.nodes.size(), &dn)) != HRPT_OK) return r;
+        if ((r = upload(c, bvh.tris.data(), bvh.tris.size(), &dt)) != HRPT_OK) return r;
+        v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
+        v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
+        v.rootLeaf = bvh.rootLeaf;
+        const HostNode4* dn4;
+        if ((r = upload(c, bvh.nodes4.data(), bvh.nodes4.size(), &dn4)) != HRPT_OK) return r;
+        v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)bvh.nodes4.size();
+        // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
+        // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
+        const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
+        if ((r = upload(c, bvh.attrs.data(), bvh.attrs.size(), &da)) != HRPT_OK) return r;
+        if ((r = upload(c, bvh.instShade.data(), bvh.instShade.size(), &dis)) != HRPT_OK) return r;
+        v.attrs = reinterpret_cast<const GpuTriAttr*>(da); v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+        v.tangents = nullptr;
+        if (!bvh.tangents.empty()) {
+            if ((r = upload(c, bvh.tangents.data(), bvh.tangents.size(), &dtg)) != HRPT_OK) return r;
+            v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the BuiltBvh staging vectors die at scope exit
+        maxDepth = bvh.maxDepth; maxDepth4 = bvh.maxDepth4;
+        c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH;
+    }
+    c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = v.nodeCount; c->buildInfo.node4Count = v.node4Count;
+    c->buildInfo.maxDepth = maxDepth; c->buildInfo.maxDepth4 = maxDepth4;
     if ((r = upload(c, s->materials, s->materialCount, &v.materials)) != HRPT_OK) return r;
     if ((r = upload(c, s->lights, s->lightCount, &v.lights)) != HRPT_OK) return r;
     v.lightCount = s->lightCount;
@@ -218,7 +265,7 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     c->view = v; c->haveScene = true;
     c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
     c->traits = SceneTraits();
-    c->traits.bvhMaxDepth = bvh.maxDepth; c->traits.bvh4MaxDepth = bvh.maxDepth4;
+    c->traits.bvhMaxDepth = maxDepth; c->traits.bvh4MaxDepth = maxDepth4;
     for (uint32_t i = 0; i < s->instanceCount; ++i) {
         const HrptMaterialConstants& m = s->materials[s->instances[i].m_MaterialIndex];
         if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;
@@ -366,6 +413,23 @@ int hrpt_resolve_device(HrptContext* c, const float* accumulationDevice, float* 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_resolve(reinterpret_cast<const float4*>(accumulationDevice), reinterpret_cast<float4*>(outputDevice), (uint32_t)pixelCount,
                               static_cast<hipStream_t>(stream)));
+    return HRPT_OK;
+}
+
+int hrpt_set_bvh_builder(HrptContext* c, int builder)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (builder != HRPT_BVH_BUILDER_HOST_SAH && builder != HRPT_BVH_BUILDER_GPU_LBVH) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_bvh_builder: unknown builder");
+    c->bvhBuilder = builder;
+    return HRPT_OK;
+}
+
+int hrpt_get_build_info(HrptContext* c, HrptBuildInfo* out)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_build_info: null out");
+    if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_get_build_info: no scene uploaded");
+    *out = c->buildInfo;
     return HRPT_OK;
 }
 

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -50,6 +50,8 @@ lib.hrpt_write_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
+lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
+lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_post_process.argtypes = [C.c_void_p, C.POINTER(S.PostParams)]
@@ -158,6 +160,15 @@ class PathTracerContext:
         """Output = accum.rgb / accum.a over caller-owned device images, asynchronously on `hip_stream` (integer handle)."""
         self._check(lib.hrpt_resolve_device(self._h, C.c_void_p(int(accumulation_ptr)), C.c_void_p(int(output_ptr)), int(pixel_count),
                                             C.c_void_p(int(hip_stream))))
+
+    def set_bvh_builder(self, builder):
+        """S.BVH_BUILDER_HOST_SAH (default) or S.BVH_BUILDER_GPU_LBVH; used by the next upload_scene."""
+        self._check(lib.hrpt_set_bvh_builder(self._h, int(builder)))
+
+    def build_info(self):
+        bi = S.BuildInfo()
+        self._check(lib.hrpt_get_build_info(self._h, C.byref(bi)))
+        return bi
 
     def stats(self):
         st = S.Stats()

@@ -94,6 +94,15 @@ class Stats(C.Structure):
                 ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("bvhMaxDepth", C.c_uint32)]
 
 
+class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
+    _fields_ = [("requestedBuilder", C.c_uint32), ("usedBuilder", C.c_uint32), ("buildMs", C.c_float), ("deviceBuildMs", C.c_float),
+                ("triangleCount", C.c_uint32), ("nodeCount", C.c_uint32), ("node4Count", C.c_uint32), ("maxDepth", C.c_uint32),
+                ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("pad", C.c_uint32 * 2)]
+
+
+BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH = 0, 1
+
+
 def default_material():
     """Scene::Material defaults, src/Scene.h:163-178."""
     m = np.zeros((), MaterialConstants)

@@ -261,6 +261,25 @@ int  hrpt_set_stream(HrptContext* ctx, void* hipStream, int useCallerStream);
 /* Device pointers of the two images (width*height float4, row-major) for zero-copy consumers
  * (the HDR post chain, RCCL all-gather). */
 int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output);
+/* ---- acceleration-structure builder --------------------------------------------------------------
+ * Scene::BuildAccelerationStructures (src/Scene.cpp:67-214) is a driver BLAS/TLAS build in the reference. Here
+ * hrpt_upload_scene builds the library's own structure either on the host (binned SAH, the default: best traversal
+ * speed, seconds for millions of triangles) or on the GPU (Morton-order LBVH: milliseconds, for large or frequently
+ * rebuilt scenes). Radiance is identical either way (the hit definition is BVH-independent). The GPU builder falls back
+ * to the host one for scenes under 8 triangles or when its tree is deeper than the traversal stacks allow. */
+#define HRPT_BVH_BUILDER_HOST_SAH 0
+#define HRPT_BVH_BUILDER_GPU_LBVH 1
+int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene */
+typedef struct HrptBuildInfo {
+    uint32_t requestedBuilder, usedBuilder;     /* HRPT_BVH_BUILDER_* */
+    float    buildMs;                           /* host wall time of the build inside hrpt_upload_scene (copies included) */
+    float    deviceBuildMs;                     /* GPU builder: device time, first kernel to last node copy; else 0 */
+    uint32_t triangleCount, nodeCount, node4Count, maxDepth, maxDepth4;
+    uint32_t mortonBits;                        /* GPU builder: Morton bits of the hierarchy (63 unless the full-code tree was too deep) */
+    uint32_t pad[2];
+} HrptBuildInfo;                                /* 48 B */
+int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
+
 /* Host read-back (synchronises). bytes must be width*height*16. */
 int  hrpt_read_accumulation(HrptContext* ctx, float* rgba, size_t bytes);
 int  hrpt_read_output(HrptContext* ctx, float* rgba, size_t bytes);

@@ -1,0 +1,28 @@
+"""Host SAH vs GPU LBVH builder: build time inside hrpt_upload_scene and the frame time it leads to (1080p, 8 spp, 4 bounces)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hobbyrenderer_amd import native, scenes, structs as S
+luts = native.precompute_atmosphere()
+cases = [("config2 cornell", lambda: scenes.config_cornell(luts, 1920, 1080)),
+         ("config4 sponza-class 100k", lambda: scenes.config_sponza_class(luts, 1920, 1080)),
+         ("sponza-class 1.1M", lambda: scenes.config_sponza_class(luts, 1920, 1080, detail=3.4, tex_size=64))]
+for name, mk in cases:
+    sc, view, pos, cfg = mk()
+    cb = scenes.fill_constants(view, pos, sc, 0, 4)
+    ref = None
+    for builder, bname in ((S.BVH_BUILDER_HOST_SAH, "host SAH"), (S.BVH_BUILDER_GPU_LBVH, "gpu LBVH")):
+        c = native.PathTracerContext(0); c.set_bvh_builder(builder); c.resize(1920, 1080)
+        ups = []
+        for r in range(3):
+            t0 = time.perf_counter(); c.upload_scene(sc); ups.append((time.perf_counter() - t0) * 1e3)
+        bi = c.build_info()
+        t = []
+        for r in range(5):
+            c.render(cb, accum_count=8); c.synchronize(); t.append(c.stats().lastRenderMs)
+        acc = c.read_accumulation()
+        if ref is None: ref = acc
+        same = np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+        print(f"{name:28s} {bname:9s} used={bi.usedBuilder} tris={bi.triangleCount} nodes={bi.nodeCount} nodes4={bi.node4Count} depth={bi.maxDepth}/{bi.maxDepth4} bits={bi.mortonBits} "
+              f"upload_ms={min(ups):.1f} build_ms={bi.buildMs:.1f} device_build_ms={bi.deviceBuildMs:.2f} frame_ms={np.median(t[1:]):.2f} same_image={same}", flush=True)
+        c.close()

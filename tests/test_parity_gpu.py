@@ -175,6 +175,60 @@ def test_forced_bvh_width(luts, width, monkeypatch):
         c.close()
 
 
+# ---- GPU-built acceleration structure: same radiance bits as with the host SAH build ----------
+def _gpu_built(luts, sc, view, pos, w, h, spp, bounces, flags=S.FRAME_DEFAULT):
+    from hobbyrenderer_amd.native import PathTracerContext
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(S.BVH_BUILDER_GPU_LBVH)
+        res = _run_both(c, sc, view, pos, w, h, spp, bounces, flags)
+        return res, c.build_info()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
+def test_gpu_bvh_builder_parity(luts, flags):
+    sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54)                       # 38 triangles: LDS-resident tree
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
+    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH and bi.triangleCount == 38 and bi.nodeCount > 0 and bi.node4Count > 0
+    _assert_parity(*res)
+    sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)              # non-opaque candidates, media
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
+    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH
+    _assert_parity(*res)
+    sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=1.0, tex_size=32)   # ~100 k triangles, textures + tangents, global tree
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
+    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH and bi.triangleCount > 90000 and bi.deviceBuildMs > 0
+    assert bi.maxDepth + 2 <= 32 and 3 * bi.maxDepth4 + 2 <= 64
+    _assert_parity(*res)
+
+
+def test_gpu_bvh_builder_small_and_degenerate(luts):
+    from hobbyrenderer_amd.native import PathTracerContext
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(S.BVH_BUILDER_GPU_LBVH)
+        sc = _one_triangle_scene(luts)                     # below the GPU builder's range: host build, same API
+        view, pos = scenes.planar_view(32, 32, position=(0.0, 0.0, -4.0))
+        _assert_parity(*_run_both(c, sc, view, pos, 32, 32, 1, 2, S.FRAME_DEFAULT))
+        assert c.build_info().requestedBuilder == S.BVH_BUILDER_GPU_LBVH and c.build_info().usedBuilder == S.BVH_BUILDER_HOST_SAH
+        # many coincident triangles (identical Morton codes): ties are split by position, the result is still exact
+        b = scenes.SceneBuilder()
+        v, i = scenes.generate_default_cube()
+        m = b.add_mesh(v, i)
+        mat = b.add_material(m_BaseColor=(0.7, 0.6, 0.5, 1))
+        for k in range(12):
+            b.add_instance(m, mat)                         # 12 identical cubes on top of each other
+        sc = b.finalize(luts)
+        _assert_parity(*_run_both(c, sc, view, pos, 32, 32, 1, 3, S.FRAME_DEFAULT))
+        assert c.build_info().usedBuilder == S.BVH_BUILDER_GPU_LBVH
+        with pytest.raises(Exception):
+            c.set_bvh_builder(7)
+    finally:
+        c.close()
+
+
 # ---- edge cases: empty / tiny scenes, odd sizes, unaligned tiles, spp batching, big BVH -------------------------
 def _empty_scene(luts):
     b = scenes.SceneBuilder()
