@@ -58,6 +58,7 @@ static_assert(sizeof(srrhi::MeshData) == 164 && sizeof(srrhi::VertexQuantized) =
 namespace SceneCache {
 
 const char* LastError() { return t_error.c_str(); }
+void SetLastError(const std::string& msg) { t_error = msg; }
 
 bool IsCacheValid(const std::filesystem::path& cachePath, const std::filesystem::path& sourcePath)
 {

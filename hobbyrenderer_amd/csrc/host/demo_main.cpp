@@ -1,7 +1,7 @@
 // hobbyrt_pt_demo -- minimal driver that takes the reference's route into the pass: build a Scene, instantiate the
 // registered renderers, run N frames of ReferencePathTracer mode, write the images. With --dump it also writes every
 // input of the boundary (scene arrays, per-frame constants) so the Python tests can feed the SAME bytes to the oracle.
-//   hobbyrt_pt_demo --scene cube|cornell --width W --height H --frames N --bounces B --out PREFIX [--dump] [--no-gpu]
+//   hobbyrt_pt_demo --scene cube|cornell | --gltf FILE [--mesh-cache]  --width W --height H --frames N --bounces B --out PREFIX [--dump] [--no-gpu]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +10,7 @@
 
 #include "../../../include/hobbyrt/ProceduralScenes.h"
 #include "../../../include/hobbyrt/Renderer.h"
+#include "../../../include/hobbyrt/SceneLoader.h"
 
 using namespace hobbyrt;
 
@@ -24,13 +25,14 @@ static bool write_file(const std::string& path, const void* data, size_t bytes)
 
 int main(int argc, char** argv)
 {
-    std::string scene = "cube", out = "demo";
+    std::string scene = "cube", out = "demo", gltf;
+    bool meshCache = false;
     uint32_t width = 256, height = 256, frames = 1, bounces = 1;
     bool dump = false, noGpu = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { return (i + 1 < argc) ? argv[++i] : ""; };
-        if (a == "--scene") scene = next(); else if (a == "--out") out = next();
+        if (a == "--scene") scene = next(); else if (a == "--out") out = next(); else if (a == "--gltf") gltf = next(); else if (a == "--mesh-cache") meshCache = true;
         else if (a == "--width") width = (uint32_t)std::atoi(next()); else if (a == "--height") height = (uint32_t)std::atoi(next());
         else if (a == "--frames") frames = (uint32_t)std::atoi(next()); else if (a == "--bounces") bounces = (uint32_t)std::atoi(next());
         else if (a == "--dump") dump = true; else if (a == "--no-gpu") noGpu = true;
@@ -38,7 +40,13 @@ int main(int argc, char** argv)
     }
     Scene& s = g_Renderer.m_Scene;
     ProjectionParams proj;
-    if (scene == "cornell") {
+    if (!gltf.empty()) {
+        // Scene::LoadScene (src/Scene.cpp:9-65): glTF (+ cooked-mesh cache) -> instances, textures, material constants, lights, first camera
+        if (!SceneLoader::LoadSceneFile(s, gltf, meshCache)) { std::fprintf(stderr, "%s\n", SceneLoader::LastError()); return 1; }
+        for (const std::string& w : SceneLoader::Warnings()) std::fprintf(stderr, "warning: %s\n", w.c_str());
+        proj = s.m_Camera.GetProjection();
+        if (s.m_Cameras.empty()) proj.aspectRatio = (float)width / (float)height;
+    } else if (scene == "cornell") {
         BuildCornellScene(s);
         s.m_Camera.SetPosition(Vector3(0.0f, 1.0f, -3.4f));
         proj.fovY = 40.0f * (XM_PI / 180.0f); proj.aspectRatio = 16.0f / 9.0f;

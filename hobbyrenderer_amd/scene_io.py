@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 
+from . import native  # noqa: F401  (loads torch's HIP runtime and libhobbyrt_pt.so, which libhobbyrt_scene.so links)
 from . import structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -98,3 +99,83 @@ def load_cooked_mesh(path):
 
 def cache_is_valid(cache_path, source_path):
     return bool(lib.hrsc_cache_is_valid(os.fsencode(cache_path), os.fsencode(source_path)))
+
+
+# ---- glTF 2.0 ingestion (hrsc_scene_*) -------------------------------------------------------------------------------
+class _TextureDesc(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class _SceneView(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertexCount", C.c_uint32), ("indices", C.c_void_p), ("indexCount", C.c_uint32),
+                ("meshData", C.c_void_p), ("meshDataCount", C.c_uint32), ("instances", C.c_void_p), ("instanceCount", C.c_uint32),
+                ("materials", C.c_void_p), ("materialCount", C.c_uint32), ("lights", C.c_void_p), ("lightCount", C.c_uint32),
+                ("textures", C.POINTER(_TextureDesc)), ("textureCount", C.c_uint32),
+                ("sunDirection", C.c_float * 3), ("sunAngularSizeDeg", C.c_float), ("cameraCount", C.c_uint32),
+                ("cameraPosition", C.c_float * 3), ("cameraYaw", C.c_float), ("cameraPitch", C.c_float), ("cameraFovY", C.c_float),
+                ("cameraAspect", C.c_float), ("cameraNearZ", C.c_float),
+                ("nodeCount", C.c_uint32), ("meshCount", C.c_uint32), ("sceneTextureCount", C.c_uint32), ("warningCount", C.c_uint32),
+                ("loadedFromMeshCache", C.c_uint32)]
+
+
+EXPORTS += ["hrsc_scene_load", "hrsc_scene_free", "hrsc_scene_view", "hrsc_scene_warning", "hrsc_decode_image", "hrsc_free_pixels"]
+lib.hrsc_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.hrsc_scene_free.argtypes = [C.c_void_p]
+lib.hrsc_scene_free.restype = None
+lib.hrsc_scene_view.argtypes = [C.c_void_p, C.POINTER(_SceneView)]
+lib.hrsc_scene_warning.argtypes = [C.c_void_p, C.c_uint32]
+lib.hrsc_scene_warning.restype = C.c_char_p
+lib.hrsc_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
+lib.hrsc_free_pixels.argtypes = [C.c_void_p]
+lib.hrsc_free_pixels.restype = None
+
+LOAD_USE_MESH_CACHE = 1
+
+
+class LoadedScene:
+    """Result of load_gltf: `arrays` (a structs.SceneArrays ready for PathTracerContext.upload_scene once LUTs are attached),
+    camera parameters, warnings."""
+
+    def __init__(self, arrays, camera, camera_count, counts, warnings, from_cache):
+        self.arrays, self.camera, self.camera_count, self.counts, self.warnings, self.from_cache = arrays, camera, camera_count, counts, warnings, from_cache
+
+
+def load_gltf(path, luts, use_mesh_cache=False):
+    """Scene::LoadScene for a .gltf / .glb file (see include/hobbyrt_scene.h). luts: the Bruneton tables for SceneArrays."""
+    h = C.c_void_p()
+    rc = lib.hrsc_scene_load(os.fsencode(path), LOAD_USE_MESH_CACHE if use_mesh_cache else 0, C.byref(h))
+    if rc != 0:
+        raise SceneFormatError(rc, lib.hrsc_last_error().decode())
+    try:
+        v = _SceneView()
+        rc = lib.hrsc_scene_view(h, C.byref(v))
+        if rc != 0:
+            raise SceneFormatError(rc, lib.hrsc_last_error().decode())
+        textures = []
+        for i in range(v.textureCount):
+            t = v.textures[i]
+            textures.append(_copy(t.rgba8, t.width * t.height * 4, np.uint8).reshape(t.height, t.width, 4) if t.rgba8 else None)
+        arrays = S.SceneArrays(_copy(v.vertices, v.vertexCount, S.VertexQuantized), _copy(v.indices, v.indexCount, np.uint32), _copy(v.meshData, v.meshDataCount, S.MeshData),
+                               _copy(v.instances, v.instanceCount, S.PerInstanceData), _copy(v.materials, v.materialCount, S.MaterialConstants),
+                               _copy(v.lights, v.lightCount, S.GPULight), luts, textures)
+        arrays.sun_direction = np.array(list(v.sunDirection), np.float32)
+        arrays.sun_angular_size_deg = float(v.sunAngularSizeDeg)
+        camera = dict(position=np.array(list(v.cameraPosition), np.float32), yaw=float(v.cameraYaw), pitch=float(v.cameraPitch), fov_y=float(v.cameraFovY),
+                      aspect=float(v.cameraAspect), near_z=float(v.cameraNearZ))
+        warnings = [lib.hrsc_scene_warning(h, i).decode() for i in range(v.warningCount)]
+        counts = dict(nodes=v.nodeCount, meshes=v.meshCount, textures=v.sceneTextureCount)
+        return LoadedScene(arrays, camera, v.cameraCount, counts, warnings, bool(v.loadedFromMeshCache))
+    finally:
+        lib.hrsc_scene_free(h)
+
+
+def decode_image(data):
+    """PNG / DDS bytes -> (H, W, 4) uint8 through the library's decoders."""
+    w, h, p = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    rc = lib.hrsc_decode_image(data, len(data), C.byref(w), C.byref(h), C.byref(p))
+    if rc != 0:
+        raise SceneFormatError(rc, lib.hrsc_last_error().decode())
+    try:
+        return _copy(p.value, w.value * h.value * 4, np.uint8).reshape(h.value, w.value, 4)
+    finally:
+        lib.hrsc_free_pixels(p)

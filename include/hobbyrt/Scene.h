@@ -62,8 +62,14 @@ public:
         int m_NodeIndex = -1;
     };
 
+    struct Camera {             // src/Scene.h:219-232
+        std::string m_Name; ProjectionParams m_Projection; int m_NodeIndex = -1;
+        float m_ExposureValue = 10.0f, m_ExposureCompensation = 0.0f, m_ExposureValueMin = -7.0f, m_ExposureValueMax = 23.0f;
+    };
+
     std::vector<Mesh> m_Meshes; std::vector<Node> m_Nodes; std::vector<Material> m_Materials; std::vector<Texture> m_Textures;
-    std::vector<Light> m_Lights;
+    std::vector<Camera> m_Cameras; std::vector<Light> m_Lights;
+    int m_SelectedCameraIndex = -1;
 
     ::hobbyrt::Camera m_Camera;
     srrhi::PlanarViewConstants m_View, m_ViewPrev;
@@ -95,6 +101,9 @@ public:
     int BuildAccelerationStructures(HrptContext* context);
 
     Vector3 GetSunDirection() const;
+    void UpdateNodeBoundingSphere(int nodeIndex);   // node sphere = mesh sphere through the node's world transform
+    // Renderer::SetCameraFromSceneCamera: position / yaw / pitch / projection of m_Camera from a scene camera's node
+    void SetCameraFromSceneCamera(const Camera& sceneCamera);
 };
 
 } // namespace hobbyrt

@@ -74,6 +74,40 @@ int  hrsc_cooked_mesh_save(const char* path, const HrscCookedMesh* mesh);
 /* SceneCache::IsCacheValid (src/SceneCache.cpp:7-20): 1 when `cachePath` exists and is not older than `sourcePath`. */
 int  hrsc_cache_is_valid(const char* cachePath, const char* sourcePath);
 
+/* ---- glTF 2.0 scene ingestion --------------------------------------------------------------
+ * Scene::LoadScene (src/Scene.cpp:9-65) without the GPU upload: SceneLoader::LoadGLTFScene (src/SceneLoader.cpp:2495-2570:
+ * materials incl. KHR_materials_transmission / ior / volume / emissive_strength / pbrSpecularGlossiness, textures + samplers,
+ * perspective cameras, KHR_lights_punctual, meshes -> VertexQuantized + LOD-0 indices, node hierarchy with RH -> LH
+ * conversion), the cooked-mesh cache next to the file when asked for, FinalizeLoadedScene (instance order), texture decode
+ * (PNG, DDS RGBA8/BC1-BC5) to RGBA8, MaterialConstantsFromMaterial, CreateAndUploadLightBuffer, first scene camera.
+ * The result is exactly the set of arrays hrpt_upload_scene takes (the Bruneton LUTs are the caller's). */
+typedef struct HrscScene HrscScene;
+#define HRSC_LOAD_USE_MESH_CACHE 1u     /* read <stem>_mesh.bin when newer than the glTF, write it after cooking otherwise */
+
+typedef struct HrscSceneView {
+    const HrptVertexQuantized* vertices;   uint32_t vertexCount;
+    const uint32_t*            indices;    uint32_t indexCount;
+    const HrptMeshData*        meshData;   uint32_t meshDataCount;
+    const HrptPerInstanceData* instances;  uint32_t instanceCount;
+    const HrptMaterialConstants* materials; uint32_t materialCount;
+    const HrptGPULight*        lights;     uint32_t lightCount;
+    const HrptTextureDesc*     textures;   uint32_t textureCount;    /* bindless table: slots 0..10 are the default textures (null here) */
+    float    sunDirection[3];              /* Scene::GetSunDirection */
+    float    sunAngularSizeDeg;            /* Scene::Light::m_AngularSize of the directional light */
+    uint32_t cameraCount;                  /* perspective cameras found; the view below is camera 0 or the default camera */
+    float    cameraPosition[3], cameraYaw, cameraPitch, cameraFovY, cameraAspect, cameraNearZ;
+    uint32_t nodeCount, meshCount, sceneTextureCount, warningCount;
+    uint32_t loadedFromMeshCache;
+} HrscSceneView;
+
+int  hrsc_scene_load(const char* path, uint32_t flags, HrscScene** out);
+void hrsc_scene_free(HrscScene* scene);
+int  hrsc_scene_view(const HrscScene* scene, HrscSceneView* out);          /* pointers stay valid until hrsc_scene_free */
+const char* hrsc_scene_warning(const HrscScene* scene, uint32_t index);   /* non-fatal findings of the load (skipped textures, ...) */
+/* PNG / DDS bytes -> RGBA8 (malloc'ed; release with hrsc_free_pixels). */
+int  hrsc_decode_image(const uint8_t* bytes, size_t byteCount, uint32_t* width, uint32_t* height, uint8_t** rgba);
+void hrsc_free_pixels(uint8_t* rgba);
+
 #ifdef __cplusplus
 }
 #endif

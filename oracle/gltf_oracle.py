@@ -1,0 +1,641 @@
+"""oracle/gltf_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Pure-Python (json + numpy + zlib) restatement of the reference's glTF 2.0 ingestion, from file to the arrays the path
+tracer consumes. Follows /root/reference/src/SceneLoader.cpp: ComputeSigmaAFromAttenuation :29-39, ComputeWorldTransforms
+:1143-1156, ProcessMaterialsAndImages :1166-1309, MaterialConstantsFromMaterial :1525-1545, ProcessCameras :1596-1621,
+ProcessLights :1623-1663, ProcessMeshes :1740-1974 and :2128-2196 (assembly), ProcessNodesAndHierarchy :2208-2317,
+CreateAndUploadLightBuffer :2435-2493; src/Scene.cpp: FinalizeLoadedScene :216-343, EnsureDefaultDirectionalLight :635-666;
+src/Scene.h GetSunDirection :336-346; src/Camera.cpp SetFromMatrix :258-276; src/TextureLoader.cpp (stb_image forced to
+RGBA8 for PNG). Only tests/ import this module.
+
+PARITY UNPINNED BY THE REFERENCE: no glTF asset, cooked output or loader test ships in the snapshot, and the third parties that
+do the arithmetic there (cgltf 1.15, meshoptimizer, stb_image, DirectXMath) are not vendored. Their published behaviour is
+restated: cgltf_accessor_read_float conversions, meshopt_quantizeSnorm / quantizeHalf / generateVertexRemap (first-use order),
+stb_image's PNG -> 8-bit RGBA conventions, XMMatrixDecompose / XMMatrixRotationQuaternion. Steps of the reference that only
+reorder vertices or triangles (optimizeVertexCache / optimizeVertexFetch), LODs and meshlets are outside this restatement, as is
+meshopt_generateTangents (absent from the tree: the standard UV-derivative construction is used, the same one the product uses).
+All arithmetic is float32 in the reference's expression order unless a line says otherwise.
+"""
+import base64
+import json
+import math
+import os
+import struct
+import urllib.parse
+import zlib
+
+import numpy as np
+
+f32 = np.float32
+F = lambda x: np.float32(x)  # noqa: E731
+
+VertexQuantized = np.dtype([("m_Pos", "<f4", 3), ("m_Normal", "<u4"), ("m_Uv", "<u4"), ("m_Tangent", "<u4")])
+MeshData = np.dtype([("m_LODCount", "<u4"), ("m_IndexOffsets", "<u4", 8), ("m_IndexCounts", "<u4", 8), ("m_MeshletOffsets", "<u4", 8),
+                     ("m_MeshletCounts", "<u4", 8), ("m_LODErrors", "<f4", 8)])
+PerInstanceData = np.dtype([("m_World", "<f4", (4, 4)), ("m_PrevWorld", "<f4", (4, 4)), ("m_MaterialIndex", "<u4"), ("m_MeshDataIndex", "<u4"),
+                            ("m_Radius", "<f4"), ("m_LODIndex", "<u4"), ("m_Center", "<f4", 3), ("m_FirstGeometryInstanceIndex", "<u4")])
+MaterialConstants = np.dtype([
+    ("m_BaseColor", "<f4", 4), ("m_EmissiveFactor", "<f4", 4), ("m_RoughnessMetallic", "<f4", 2), ("m_TextureFlags", "<u4"),
+    ("m_AlbedoTextureIndex", "<u4"), ("m_NormalTextureIndex", "<u4"), ("m_RoughnessMetallicTextureIndex", "<u4"), ("m_EmissiveTextureIndex", "<u4"),
+    ("m_AlbedoSamplerIndex", "<u4"), ("m_NormalSamplerIndex", "<u4"), ("m_RoughnessSamplerIndex", "<u4"), ("m_EmissiveSamplerIndex", "<u4"),
+    ("m_AlbedoMinMipIndex", "<u4"), ("m_NormalMinMipIndex", "<u4"), ("m_RoughnessMinMipIndex", "<u4"), ("m_EmissiveMinMipIndex", "<u4"),
+    ("m_AlbedoFeedbackIndex", "<u4"), ("m_NormalFeedbackIndex", "<u4"), ("m_RoughnessFeedbackIndex", "<u4"), ("m_EmissiveFeedbackIndex", "<u4"),
+    ("m_MinMipDimsX", "<u4"), ("m_MinMipDimsY", "<u4"), ("m_AlphaMode", "<u4"), ("m_AlphaCutoff", "<f4"), ("m_IOR", "<f4"),
+    ("m_TransmissionFactor", "<f4"), ("m_ThicknessFactor", "<f4"), ("m_AttenuationDistance", "<f4"), ("m_AttenuationColor", "<f4", 3),
+    ("m_SigmaA", "<f4", 3), ("m_IsThinSurface", "<u4"), ("m_SigmaS", "<f4", 3)])
+GPULight = np.dtype([("m_Position", "<f4", 3), ("m_Intensity", "<f4"), ("m_Direction", "<f4", 3), ("m_Type", "<u4"), ("m_Color", "<f4", 3),
+                     ("m_Range", "<f4"), ("m_SpotInnerConeAngle", "<f4"), ("m_SpotOuterConeAngle", "<f4"), ("m_Radius", "<f4"), ("m_CosSunAngularRadius", "<f4")])
+assert VertexQuantized.itemsize == 24 and MeshData.itemsize == 164 and PerInstanceData.itemsize == 160 and MaterialConstants.itemsize == 180 and GPULight.itemsize == 64
+
+ALPHA_OPAQUE, ALPHA_MASK, ALPHA_BLEND = 0, 1, 2
+TEX_BLACK, TEX_WHITE, TEX_GRAY, TEX_NORMAL, TEX_PBR, DEFAULT_TEXTURE_COUNT = 0, 1, 2, 3, 4, 11
+LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_SPOT = 0, 1, 2
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+# ---------------------------------------------------------------- meshoptimizer inline quantisers
+def quantize_snorm(v, bits):
+    scale = f32((1 << (bits - 1)) - 1)
+    v = f32(v)
+    rnd = f32(0.5) if v >= 0 else f32(-0.5)
+    v = v if v >= f32(-1) else f32(-1)
+    v = v if v <= f32(1) else f32(1)
+    return int(f32(v * scale) + rnd)            # C int conversion truncates toward zero
+
+
+def quantize_half(v):
+    ui = int(np.float32(v).view(np.uint32))
+    s = (ui >> 16) & 0x8000
+    em = ui & 0x7FFFFFFF
+    h = (em - (112 << 23) + (1 << 12)) >> 13
+    if em < (113 << 23):
+        h = 0
+    if em >= (143 << 23):
+        h = 0x7C00
+    if em > (255 << 23):
+        h = 0x7E00
+    return (s | h) & 0xFFFF
+
+
+def quantize_vertex(pos, nrm, uv, tan):
+    """src/SceneLoader.cpp:1946-1974"""
+    out = np.zeros((), VertexQuantized)
+    out["m_Pos"] = pos
+    n = 0
+    for k in range(3):
+        n |= (quantize_snorm(nrm[k], 10) + 511) << (10 * k)
+    if not (f32(tan[3]) >= 0):
+        n |= 1 << 30
+    out["m_Normal"] = n
+    out["m_Uv"] = quantize_half(uv[0]) | (quantize_half(uv[1]) << 16)
+    tx, ty, tz = f32(tan[0]), f32(tan[1]), f32(tan[2])
+    tsum = f32(f32(abs(tx) + abs(ty)) + abs(tz))
+    t = 0
+    if tsum > f32(1e-6):
+        if tz >= 0:
+            tu, tv = f32(tx / tsum), f32(ty / tsum)
+        else:
+            tu = f32(f32(f32(1.0) - abs(f32(ty / tsum))) * (f32(1.0) if tx >= 0 else f32(-1.0)))
+            tv = f32(f32(f32(1.0) - abs(f32(tx / tsum))) * (f32(1.0) if ty >= 0 else f32(-1.0)))
+        t = (quantize_snorm(tu, 8) + 127) | ((quantize_snorm(tv, 8) + 127) << 8)
+    out["m_Tangent"] = t
+    return out
+
+
+# ---------------------------------------------------------------- PNG (stb_image conventions, forced to 4 channels)
+def decode_png(data):
+    assert data[:8] == b"\x89PNG\r\n\x1a\n", "not a PNG"
+    off, idat, plte, trns, ihdr = 8, b"", None, None, None
+    while off + 12 <= len(data):
+        ln, typ = struct.unpack_from(">I4s", data, off)
+        body = data[off + 8:off + 8 + ln]
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"PLTE":
+            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif typ == b"tRNS":
+            trns = body
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            break
+        off += 12 + ln
+    w, h, depth, ctype, _, _, interlace = ihdr
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8)
+    bits = channels * depth
+    bpp = max(1, bits // 8)
+    samples = np.zeros((h, w, channels), np.uint16)
+
+    def unfilter(block, rows, stride):
+        out = np.zeros((rows, stride), np.uint8)
+        prev = np.zeros(stride, np.int32)
+        for y in range(rows):
+            line = block[y * (stride + 1):(y + 1) * (stride + 1)]
+            ft, x = int(line[0]), line[1:].astype(np.int32)
+            cur = np.zeros(stride, np.int32)
+            if ft == 0:
+                cur = x
+            elif ft == 2:
+                cur = (x + prev) & 255
+            else:
+                for i in range(stride):
+                    a = cur[i - bpp] if i >= bpp else 0
+                    b = prev[i]
+                    c = prev[i - bpp] if i >= bpp else 0
+                    if ft == 1:
+                        p = a
+                    elif ft == 3:
+                        p = (a + b) >> 1
+                    else:
+                        pp = a + b - c
+                        pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                        p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                    cur[i] = (x[i] + p) & 255
+            out[y] = cur
+            prev = cur
+        return out
+
+    def unpack(rows, pw, ph, x0, y0, dx, dy):
+        for y in range(ph):
+            r = rows[y]
+            if depth == 8:
+                vals = r[:pw * channels].astype(np.uint16)
+            elif depth == 16:
+                vals = (r[0:2 * pw * channels:2].astype(np.uint16) << 8) | r[1:2 * pw * channels:2]
+            else:
+                bitsarr = np.unpackbits(r)[:pw * channels * depth].reshape(-1, depth)
+                vals = np.zeros(pw * channels, np.uint16)
+                for b in range(depth):
+                    vals = (vals << 1) | bitsarr[:, b]
+            samples[y0 + y * dy, x0:x0 + pw * dx:dx, :] = vals.reshape(pw, channels)
+
+    if not interlace:
+        stride = (w * bits + 7) // 8
+        unpack(unfilter(raw, h, stride), w, h, 0, 0, 1, 1)
+    else:
+        pos = 0
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            pw = (w - x0 + dx - 1) // dx if w > x0 else 0
+            ph = (h - y0 + dy - 1) // dy if h > y0 else 0
+            if not pw or not ph:
+                continue
+            stride = (pw * bits + 7) // 8
+            unpack(unfilter(raw[pos:pos + (stride + 1) * ph], ph, stride), pw, ph, x0, y0, dx, dy)
+            pos += (stride + 1) * ph
+    out = np.full((h, w, 4), 255, np.uint8)
+    to8 = (lambda v: (v >> 8).astype(np.uint8)) if depth == 16 else (lambda v: v.astype(np.uint8))
+    if ctype == 0:
+        g = (samples[..., 0] * {1: 255, 2: 85, 4: 17}.get(depth, 1)).astype(np.uint16)
+        out[..., 0] = out[..., 1] = out[..., 2] = to8(g) if depth >= 8 else g.astype(np.uint8)
+        if trns is not None and len(trns) >= 2:
+            out[..., 3] = np.where(samples[..., 0] == struct.unpack(">H", trns[:2])[0], 0, 255)
+    elif ctype == 2:
+        out[..., :3] = to8(samples)
+        if trns is not None and len(trns) >= 6:
+            key = np.array(struct.unpack(">HHH", trns[:6]), np.uint16)
+            out[..., 3] = np.where((samples == key).all(-1), 0, 255)
+    elif ctype == 3:
+        out[..., :3] = plte[samples[..., 0]]
+        if trns is not None:
+            a = np.full(256, 255, np.uint8)
+            a[:len(trns)] = np.frombuffer(trns, np.uint8)
+            out[..., 3] = a[samples[..., 0]]
+    elif ctype == 4:
+        out[..., 0] = out[..., 1] = out[..., 2] = to8(samples[..., 0])
+        out[..., 3] = to8(samples[..., 1])
+    else:
+        out[...] = to8(samples)
+    return out
+
+
+# ---------------------------------------------------------------- glTF document
+_COMP = {5120: ("<i1", 1), 5121: ("<u1", 1), 5122: ("<i2", 2), 5123: ("<u2", 2), 5125: ("<u4", 4), 5126: ("<f4", 4)}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}
+
+
+class Document:
+    def __init__(self, path):
+        self.dir = os.path.dirname(path)
+        data = open(path, "rb").read()
+        self.bin = None
+        if data[:4] == b"glTF":
+            _, version, total = struct.unpack_from("<4sII", data, 0)
+            assert version == 2
+            off = 12
+            while off + 8 <= total:
+                ln, typ = struct.unpack_from("<II", data, off)
+                chunk = data[off + 8:off + 8 + ln]
+                if typ == 0x4E4F534A:
+                    self.j = json.loads(chunk.decode("utf-8"))
+                elif typ == 0x004E4942:
+                    self.bin = chunk
+                off += 8 + ln
+        else:
+            self.j = json.loads(data.decode("utf-8-sig"))
+        self.buffers = []
+        for i, b in enumerate(self.j.get("buffers", [])):
+            uri = b.get("uri")
+            if uri is None:
+                self.buffers.append(self.bin)
+            elif uri.startswith("data:"):
+                self.buffers.append(base64.b64decode(uri.split(",", 1)[1]))
+            else:
+                self.buffers.append(open(os.path.join(self.dir, urllib.parse.unquote(uri)), "rb").read())
+
+    def accessor(self, index):
+        """cgltf_accessor_read_float over the whole accessor: float32 array (count, components)."""
+        a = self.j["accessors"][index]
+        dt, size = _COMP[a["componentType"]]
+        n = _NCOMP[a["type"]]
+        if "bufferView" not in a:
+            return np.zeros((a["count"], n), np.float32), np.zeros((a["count"], n), np.uint32)
+        v = self.j["bufferViews"][a["bufferView"]]
+        base = v.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = v.get("byteStride", 0) or size * n
+        buf = self.buffers[v["buffer"]]
+        rows = np.zeros((a["count"], n), dt)
+        for i in range(a["count"]):
+            rows[i] = np.frombuffer(buf, dt, n, base + i * stride)
+        if a["componentType"] == 5126:
+            fl = rows.astype(np.float32)
+        elif a.get("normalized", False):
+            denom = {5120: 127.0, 5121: 255.0, 5122: 32767.0, 5123: 65535.0}[a["componentType"]]
+            fl = (rows.astype(np.float32) / f32(denom)).astype(np.float32)
+            if a["componentType"] in (5120, 5122):
+                fl = np.maximum(fl, f32(-1.0))
+        else:
+            fl = rows.astype(np.float32)
+        return fl, rows.astype(np.uint32) if a["componentType"] in (5121, 5123, 5125) else None
+
+
+def compute_sigma_a(distance, color):
+    """:29-39 (std::log on float: a 1-ulp libm difference is possible, tests compare with a tolerance)."""
+    if distance <= 0.0 or distance >= FLT_MAX / 2.0:
+        return np.zeros(3, np.float32)
+    return np.array([min(f32(-np.log(max(f32(c), f32(1e-6)))) / f32(distance), f32(100.0)) for c in color], np.float32)
+
+
+def _texref(info, offset=0):
+    return info["index"] + offset if isinstance(info, dict) and "index" in info else -1
+
+
+def process_materials(doc):
+    mats, cpu = [], []
+    for m in doc.j.get("materials", []):
+        g = np.zeros((), MaterialConstants)
+        g["m_BaseColor"] = (1, 1, 1, 1); g["m_EmissiveFactor"] = (0, 0, 0, 1); g["m_RoughnessMetallic"] = (1, 0)
+        g["m_AlbedoTextureIndex"] = TEX_WHITE; g["m_NormalTextureIndex"] = TEX_NORMAL; g["m_RoughnessMetallicTextureIndex"] = TEX_PBR
+        g["m_EmissiveTextureIndex"] = TEX_BLACK; g["m_AlphaMode"] = ALPHA_OPAQUE; g["m_AlphaCutoff"] = 0.5; g["m_IOR"] = 1.5
+        g["m_AttenuationDistance"] = FLT_MAX; g["m_AttenuationColor"] = (1, 1, 1)
+        ext = m.get("extensions", {})
+        refs = {"base": -1, "normal": -1, "mr": -1, "emissive": -1}
+        if "KHR_materials_pbrSpecularGlossiness" in ext:
+            sg = ext["KHR_materials_pbrSpecularGlossiness"]
+            g["m_BaseColor"] = sg.get("diffuseFactor", [1, 1, 1, 1])
+            g["m_RoughnessMetallic"][0] = f32(1.0) - f32(sg.get("glossinessFactor", 1.0))
+            g["m_RoughnessMetallic"][1] = max(f32(x) for x in sg.get("specularFactor", [1, 1, 1]))
+            refs["base"] = _texref(sg.get("diffuseTexture")); refs["mr"] = _texref(sg.get("specularGlossinessTexture"))
+        elif "pbrMetallicRoughness" in m:
+            p = m["pbrMetallicRoughness"]
+            g["m_BaseColor"] = p.get("baseColorFactor", [1, 1, 1, 1])
+            refs["base"] = _texref(p.get("baseColorTexture")); refs["mr"] = _texref(p.get("metallicRoughnessTexture"))
+            metallic = f32(p.get("metallicFactor", 1.0))
+            if refs["mr"] == -1 and metallic == f32(1.0):
+                metallic = f32(0.0)
+            g["m_RoughnessMetallic"] = (p.get("roughnessFactor", 1.0), metallic)
+        refs["normal"] = _texref(m.get("normalTexture")); refs["emissive"] = _texref(m.get("emissiveTexture"))
+        e = np.array(m.get("emissiveFactor", [0, 0, 0]), np.float32)
+        if "KHR_materials_emissive_strength" in ext:
+            e = (e * f32(ext["KHR_materials_emissive_strength"].get("emissiveStrength", 1.0))).astype(np.float32)
+        g["m_EmissiveFactor"] = (e[0], e[1], e[2], 1.0)
+        mode = m.get("alphaMode", "OPAQUE")
+        if mode == "MASK":
+            g["m_AlphaMode"] = ALPHA_MASK; g["m_AlphaCutoff"] = m.get("alphaCutoff", 0.5)
+        elif mode == "BLEND":
+            g["m_AlphaMode"] = ALPHA_BLEND
+        if "KHR_materials_transmission" in ext:
+            g["m_AlphaMode"] = ALPHA_BLEND; g["m_TransmissionFactor"] = ext["KHR_materials_transmission"].get("transmissionFactor", 0.0)
+        if "KHR_materials_ior" in ext:
+            g["m_IOR"] = ext["KHR_materials_ior"].get("ior", 1.5)
+        if "KHR_materials_volume" in ext:
+            v = ext["KHR_materials_volume"]
+            g["m_ThicknessFactor"] = v.get("thicknessFactor", 0.0); g["m_AttenuationDistance"] = v.get("attenuationDistance", FLT_MAX)
+            g["m_AttenuationColor"] = v.get("attenuationColor", [1, 1, 1])
+            g["m_IsThinSurface"] = 1 if f32(v.get("thicknessFactor", 0.0)) == 0 else 0
+            g["m_SigmaA"] = compute_sigma_a(float(g["m_AttenuationDistance"]), g["m_AttenuationColor"])
+        mats.append(g); cpu.append(refs)
+    return mats, cpu
+
+
+def process_textures(doc):
+    out = []
+    images, samplers = doc.j.get("images", []), doc.j.get("samplers", [])
+    for t in doc.j.get("textures", []):
+        uri = images[t["source"]].get("uri", "") if "source" in t else ""
+        if uri and os.path.exists(os.path.join(doc.dir, os.path.splitext(uri)[0] + ".dds")):
+            uri = os.path.splitext(uri)[0] + ".dds"
+        wrap = True
+        if "sampler" in t:
+            s = samplers[t["sampler"]]
+            wrap = s.get("wrapS", 10497) == 10497 or s.get("wrapT", 10497) == 10497
+        out.append({"uri": uri, "sampler": 1 if wrap else 0, "bindless": None, "pixels": None})
+    return out
+
+
+def generate_tangents(idx, pos, nrm, uv):
+    out = np.zeros((len(idx), 4), np.float32)
+    for t in range(0, len(idx) - 2, 3):
+        a, b, c = idx[t], idx[t + 1], idx[t + 2]
+        e1 = (pos[b] - pos[a]).astype(np.float32); e2 = (pos[c] - pos[a]).astype(np.float32)
+        du1, dv1 = f32(uv[b][0] - uv[a][0]), f32(uv[b][1] - uv[a][1])
+        du2, dv2 = f32(uv[c][0] - uv[a][0]), f32(uv[c][1] - uv[a][1])
+        det = f32(f32(du1 * dv2) - f32(du2 * dv1))
+        if det != 0:
+            r = f32(f32(1.0) / det)
+            T = ((e1 * dv2).astype(np.float32) - (e2 * dv1).astype(np.float32)).astype(np.float32) * r
+            B = ((e2 * du1).astype(np.float32) - (e1 * du2).astype(np.float32)).astype(np.float32) * r
+            T, B = T.astype(np.float32), B.astype(np.float32)
+        else:
+            T, B = np.array([1, 0, 0], np.float32), np.array([0, 1, 0], np.float32)
+        for corner in range(3):
+            n = nrm[idx[t + corner]]
+            d = f32(f32(f32(T[0] * n[0]) + f32(T[1] * n[1])) + f32(T[2] * n[2]))
+            o = np.array([f32(T[k] - f32(n[k] * d)) for k in range(3)], np.float32)
+            ln = np.sqrt(f32(f32(f32(o[0] * o[0]) + f32(o[1] * o[1])) + f32(o[2] * o[2])))
+            o = (o / ln).astype(np.float32) if ln > 0 else np.array([1, 0, 0], np.float32)
+            cx = f32(f32(n[1] * o[2]) - f32(n[2] * o[1])); cy = f32(f32(n[2] * o[0]) - f32(n[0] * o[2])); cz = f32(f32(n[0] * o[1]) - f32(n[1] * o[0]))
+            w = f32(-1.0) if f32(f32(f32(cx * B[0]) + f32(cy * B[1])) + f32(cz * B[2])) < 0 else f32(1.0)
+            out[t + corner] = (o[0], o[1], o[2], w)
+    return out
+
+
+def process_primitive(doc, prim, materials_cpu):
+    attrs = prim.get("attributes", {})
+    if "POSITION" not in attrs or prim.get("mode", 4) != 4:
+        return None
+    mat = prim.get("material", -1)
+    has_n, has_uv, has_t = "NORMAL" in attrs, "TEXCOORD_0" in attrs, "TANGENT" in attrs
+    if not has_t and (not has_n or not has_uv) and mat >= 0:
+        materials_cpu[mat]["normal"] = -1
+    pos = doc.accessor(attrs["POSITION"])[0][:, :3].copy()
+    nv = len(pos)
+    nrm = doc.accessor(attrs["NORMAL"])[0][:, :3].copy() if has_n else np.zeros((nv, 3), np.float32)
+    uv = doc.accessor(attrs["TEXCOORD_0"])[0][:, :2].copy() if has_uv else np.zeros((nv, 2), np.float32)
+    tan = doc.accessor(attrs["TANGENT"])[0][:, :4].copy() if has_t else np.zeros((nv, 4), np.float32)
+    pos[:, 2] = -pos[:, 2]; nrm[:, 2] = -nrm[:, 2]; tan[:, 2] = -tan[:, 2]; tan[:, 3] = -tan[:, 3]
+    if "indices" in prim:
+        idx = doc.accessor(prim["indices"])[1][:, 0].astype(np.int64)
+    else:
+        idx = np.arange(nv, dtype=np.int64)
+    idx = idx[:len(idx) - len(idx) % 3].copy()
+    idx[1::3], idx[2::3] = idx[2::3].copy(), idx[1::3].copy()
+    # degenerate / duplicate filter (:1879)
+    keep, seen = [], set()
+    for t in range(0, len(idx), 3):
+        r = idx[t:t + 3]
+        if (r >= nv).any():
+            continue
+        p = [pos[i].tobytes() for i in r]
+        if p[0] == p[1] or p[1] == p[2] or p[0] == p[2]:
+            continue
+        first = min(range(3), key=lambda k: (p[k], k))
+        key = b"".join(p[(first + k) % 3] for k in range(3))
+        if key in seen:
+            continue
+        seen.add(key)
+        keep.extend(r.tolist())
+    idx = np.array(keep, np.int64)
+    raw = np.zeros(nv, np.dtype([("pos", "<f4", 3), ("nrm", "<f4", 3), ("uv", "<f4", 2), ("tan", "<f4", 4)]))
+    raw["pos"], raw["nrm"], raw["uv"], raw["tan"] = pos, nrm, uv, tan
+    raw = list(raw)
+    if not has_t and has_n and has_uv:
+        tangents = generate_tangents(idx, pos, nrm, uv)
+        for i, v in enumerate(idx):
+            raw[v] = raw[v].copy(); raw[v]["tan"] = tangents[i]
+        splits = [-1] * len(raw)
+        for i in range(len(idx)):
+            v, target = int(idx[i]), tangents[i].tobytes()
+            while v != -1 and raw[v]["tan"].tobytes() != target:
+                v = splits[v]
+            if v == -1:
+                v = len(raw)
+                cp = raw[int(idx[i])].copy(); cp["tan"] = tangents[i]
+                raw.append(cp)
+                splits.append(splits[int(idx[i])]); splits[int(idx[i])] = v
+            idx[i] = v
+    unique, verts, local = {}, [], []
+    for i in idx:
+        k = raw[int(i)].tobytes()
+        if k not in unique:
+            unique[k] = len(verts); verts.append(raw[int(i)])
+        local.append(unique[k])
+    vq = np.array([quantize_vertex(v["pos"], v["nrm"], v["uv"], v["tan"]) for v in verts], VertexQuantized) if verts else np.zeros(0, VertexQuantized)
+    return {"vertices": vq, "indices": np.array(local, np.uint32), "material": mat}
+
+
+# ---------------------------------------------------------------- transforms (float32, DirectXMath conventions)
+def matrix_from_trs(t, q, s):
+    x, y, z, w = (f32(v) for v in q)
+    two, one = f32(2), f32(1)
+    r = np.identity(4, dtype=np.float32)
+    r[0, 0] = one - two * f32(f32(y * y) + f32(z * z)); r[0, 1] = two * f32(f32(x * y) + f32(z * w)); r[0, 2] = two * f32(f32(x * z) - f32(y * w))
+    r[1, 0] = two * f32(f32(x * y) - f32(z * w)); r[1, 1] = one - two * f32(f32(x * x) + f32(z * z)); r[1, 2] = two * f32(f32(y * z) + f32(x * w))
+    r[2, 0] = two * f32(f32(x * z) + f32(y * w)); r[2, 1] = two * f32(f32(y * z) - f32(x * w)); r[2, 2] = one - two * f32(f32(x * x) + f32(y * y))
+    for i in range(3):
+        r[i, :3] = (r[i, :3] * f32(s[i])).astype(np.float32)
+    r[3, :3] = t
+    return r
+
+
+def decompose(m):
+    m = np.asarray(m, np.float32)
+    t = m[3, :3].copy()
+    ln = [np.sqrt(f32(f32(f32(m[i, 0] * m[i, 0]) + f32(m[i, 1] * m[i, 1])) + f32(m[i, 2] * m[i, 2]))) for i in range(3)]
+    r = np.zeros((3, 3), np.float32)
+    for i in range(3):
+        r[i] = (m[i, :3] / ln[i]).astype(np.float32) if ln[i] > 0 else np.identity(3, dtype=np.float32)[i]
+    c = lambda a, b: f32(a * b)  # noqa: E731
+    det = f32(f32(c(r[0, 0], f32(c(r[1, 1], r[2, 2]) - c(r[1, 2], r[2, 1]))) - c(r[0, 1], f32(c(r[1, 0], r[2, 2]) - c(r[1, 2], r[2, 0])))) +
+              c(r[0, 2], f32(c(r[1, 0], r[2, 1]) - c(r[1, 1], r[2, 0]))))
+    if det < 0:
+        a = (0 if ln[0] >= ln[2] else 2) if ln[0] >= ln[1] else (1 if ln[1] >= ln[2] else 2)
+        ln[a] = -ln[a]; r[a] = -r[a]
+    tr = f32(f32(r[0, 0] + r[1, 1]) + r[2, 2])
+    if tr > 0:
+        s = f32(np.sqrt(f32(tr + f32(1))) * f32(2)); w = f32(f32(0.25) * s)
+        x = f32(f32(r[1, 2] - r[2, 1]) / s); y = f32(f32(r[2, 0] - r[0, 2]) / s); z = f32(f32(r[0, 1] - r[1, 0]) / s)
+    elif r[0, 0] > r[1, 1] and r[0, 0] > r[2, 2]:
+        s = f32(np.sqrt(f32(f32(f32(f32(1) + r[0, 0]) - r[1, 1]) - r[2, 2])) * f32(2))
+        w = f32(f32(r[1, 2] - r[2, 1]) / s); x = f32(f32(0.25) * s); y = f32(f32(r[0, 1] + r[1, 0]) / s); z = f32(f32(r[0, 2] + r[2, 0]) / s)
+    elif r[1, 1] > r[2, 2]:
+        s = f32(np.sqrt(f32(f32(f32(f32(1) + r[1, 1]) - r[0, 0]) - r[2, 2])) * f32(2))
+        w = f32(f32(r[2, 0] - r[0, 2]) / s); x = f32(f32(r[0, 1] + r[1, 0]) / s); y = f32(f32(0.25) * s); z = f32(f32(r[1, 2] + r[2, 1]) / s)
+    else:
+        s = f32(np.sqrt(f32(f32(f32(f32(1) + r[2, 2]) - r[0, 0]) - r[1, 1])) * f32(2))
+        w = f32(f32(r[0, 1] - r[1, 0]) / s); x = f32(f32(r[0, 2] + r[2, 0]) / s); y = f32(f32(r[1, 2] + r[2, 1]) / s); z = f32(f32(0.25) * s)
+    return np.array(ln, np.float32), np.array([x, y, z, w], np.float32), t
+
+
+def matmul(a, b):
+    """hobbyrt::MatrixMultiply: float64 accumulation in k order, one rounding to float32."""
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            s = 0.0
+            for k in range(4):
+                s += float(a[i, k]) * float(b[k, j])
+            out[i, j] = f32(s)
+    return out
+
+
+def normalize3(v):
+    v = np.asarray(v, np.float32)
+    ln = np.sqrt(f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2])))
+    return (v / ln).astype(np.float32) if ln > 0 else v
+
+
+def transform_normal(v, m):
+    return np.array([f32(f32(f32(v[0] * m[0, k]) + f32(v[1] * m[1, k])) + f32(v[2] * m[2, k])) for k in range(3)], np.float32)
+
+
+# ---------------------------------------------------------------- whole load
+def load(path):
+    doc = Document(path)
+    j = doc.j
+    materials, mat_cpu = process_materials(doc)
+    textures = process_textures(doc)
+    cameras = []
+    for c in j.get("cameras", []):
+        if c.get("type") != "perspective":
+            continue
+        p = c["perspective"]
+        cameras.append({"aspect": f32(p["aspectRatio"]) if "aspectRatio" in p else f32(16.0) / f32(9.0), "fovY": f32(p.get("yfov", 0.0)), "nearZ": f32(p.get("znear", 0.0)), "node": -1})
+    lights = []
+    for l in j.get("extensions", {}).get("KHR_lights_punctual", {}).get("lights", []):
+        ty = {"directional": LIGHT_DIRECTIONAL, "point": LIGHT_POINT, "spot": LIGHT_SPOT}.get(l.get("type"))
+        if ty is None:
+            continue
+        spot = l.get("spot", {})
+        lights.append({"type": ty, "color": l.get("color", [1, 1, 1]), "intensity": l.get("intensity", 1.0), "range": l.get("range", 0.0), "radius": 0.0,
+                       "inner": spot.get("innerConeAngle", 0.0), "outer": f32(spot.get("outerConeAngle", 3.14159265358979323846 / 4.0)), "angular": 0.533, "node": -1})
+    # meshes
+    vertices, indices, mesh_data, meshes = [], [], [], []
+    voff = ioff = 0
+    for m in j.get("meshes", []):
+        prims = []
+        for prim in m.get("primitives", []):
+            res = process_primitive(doc, prim, mat_cpu)
+            md = np.zeros((), MeshData)
+            mat = prim.get("material", -1)
+            if res is not None and len(res["indices"]):
+                md["m_LODCount"] = 1; md["m_IndexOffsets"][0] = ioff; md["m_IndexCounts"][0] = len(res["indices"])
+            if res is not None:
+                vertices.append(res["vertices"]); indices.append(res["indices"] + np.uint32(voff))
+                prims.append({"material": mat, "mesh_data": len(mesh_data)})
+                voff += len(res["vertices"]); ioff += len(res["indices"])
+            else:
+                prims.append({"material": mat, "mesh_data": len(mesh_data)})
+            mesh_data.append(md)
+        meshes.append(prims)
+    # sort lights (Spot, Point, Directional), ensure the default sun, nodes
+    nodes_json = j.get("nodes", [])
+    nodes = [{"mesh": n.get("mesh", -1), "camera": n.get("camera", -1), "light": n.get("extensions", {}).get("KHR_lights_punctual", {}).get("light", -1),
+              "children": list(n.get("children", [])), "parent": -1, "t": np.zeros(3, np.float32), "q": np.array([0, 0, 0, 1], np.float32), "s": np.ones(3, np.float32)} for n in nodes_json]
+    order = sorted(range(len(lights)), key=lambda i: -lights[i]["type"])            # stable: a.type > b.type
+    remap = {old: new for new, old in enumerate(order)}
+    lights = [lights[i] for i in order]
+    if not lights or lights[-1]["type"] != LIGHT_DIRECTIONAL:
+        lights.append({"type": LIGHT_DIRECTIONAL, "color": [1, 1, 1], "intensity": 1.0, "range": 0.0, "radius": 0.0, "inner": 0.0, "outer": f32(0.785398163), "angular": 0.533, "node": len(nodes)})
+        cp, sp = math.cos(float(f32(0.785398163))), math.sin(float(f32(0.785398163)))
+        world = np.identity(4, dtype=np.float32)
+        world[1, 1] = f32(cp); world[1, 2] = f32(sp); world[2, 1] = f32(-sp); world[2, 2] = f32(cp)
+        nodes.append({"mesh": -1, "camera": -1, "light": len(lights) - 1, "children": [], "parent": -1, "local": world, "world": world, "fixed": True})
+    # NOTE: the reference sorts m_Lights inside EnsureDefaultDirectionalLight BEFORE node light indices are resolved (:2542-2545 then
+    # ProcessNodesAndHierarchy), so a node's light index addresses the SORTED list; the product does the same. `remap` is therefore unused.
+    del remap
+    for ni, n in enumerate(nodes_json):
+        node = nodes[ni]
+        if "matrix" in n and len(n["matrix"]) == 16:
+            s, q, t = decompose(np.array(n["matrix"], np.float32).reshape(4, 4))
+            t[2] = -t[2]; q[0] = -q[0]; q[1] = -q[1]
+            node["t"], node["q"], node["s"] = t, q, s
+        else:
+            if len(n.get("translation", [])) == 3:
+                node["t"] = np.array([n["translation"][0], n["translation"][1], -f32(n["translation"][2])], np.float32)
+            if len(n.get("scale", [])) == 3:
+                node["s"] = np.array(n["scale"], np.float32)
+            if len(n.get("rotation", [])) == 4:
+                r = n["rotation"]
+                node["q"] = np.array([-f32(r[0]), -f32(r[1]), r[2], r[3]], np.float32)
+        node["local"] = matrix_from_trs(node["t"], node["q"], node["s"]); node["world"] = node["local"]
+    for ni, n in enumerate(nodes_json):
+        for c in nodes[ni]["children"]:
+            nodes[c]["parent"] = ni
+    for ni in range(len(nodes_json)):
+        if 0 <= nodes[ni]["camera"] < len(cameras):
+            cameras[nodes[ni]["camera"]]["node"] = ni
+        if 0 <= nodes[ni]["light"] < len(lights):
+            lights[nodes[ni]["light"]]["node"] = ni
+
+    def walk(ni, parent):
+        nodes[ni]["world"] = matmul(nodes[ni]["local"], parent)
+        for c in nodes[ni]["children"]:
+            walk(c, nodes[ni]["world"])
+    for ni in range(len(nodes_json)):
+        if nodes[ni]["parent"] == -1:
+            walk(ni, np.identity(4, dtype=np.float32))
+    # FinalizeLoadedScene: one instance per (node, primitive); buckets opaque / masked / transparent, static before dynamic
+    buckets = [[] for _ in range(6)]
+    for ni, node in enumerate(nodes):
+        if node["mesh"] < 0:
+            continue
+        for prim in meshes[node["mesh"]]:
+            inst = np.zeros((), PerInstanceData)
+            inst["m_World"] = node["world"]; inst["m_PrevWorld"] = node["world"]
+            inst["m_MaterialIndex"] = np.uint32(prim["material"] & 0xFFFFFFFF); inst["m_MeshDataIndex"] = prim["mesh_data"]
+            alpha = int(materials[prim["material"]]["m_AlphaMode"]) if prim["material"] >= 0 else ALPHA_OPAQUE
+            dynamic = node["light"] != -1
+            buckets[(0 if alpha == ALPHA_OPAQUE else 2 if alpha == ALPHA_MASK else 4) + (1 if dynamic else 0)].append(inst)
+    instances = np.array([i for b in buckets for i in b], PerInstanceData) if any(buckets) else np.zeros(0, PerInstanceData)
+    # textures -> RGBA8 + bindless indices, then material constants
+    nxt = DEFAULT_TEXTURE_COUNT
+    for t in textures:
+        full = os.path.join(doc.dir, urllib.parse.unquote(t["uri"])) if t["uri"] and not t["uri"].startswith("data:") else None
+        if full and os.path.exists(full) and open(full, "rb").read(8)[:4] == b"\x89PNG":
+            t["pixels"] = decode_png(open(full, "rb").read()); t["bindless"] = nxt; nxt += 1
+    out_mats = np.zeros(len(materials), MaterialConstants)
+    for i, (g, refs) in enumerate(zip(materials, mat_cpu)):
+        for k in refs:
+            if refs[k] != -1 and (refs[k] >= len(textures) or textures[refs[k]]["bindless"] is None):
+                refs[k] = -1
+        flags = (1 if refs["base"] != -1 else 0) | (2 if refs["normal"] != -1 else 0) | (4 if refs["mr"] != -1 else 0) | (8 if refs["emissive"] != -1 else 0)
+        g["m_TextureFlags"] = flags
+        for field, smp, key in (("m_AlbedoTextureIndex", "m_AlbedoSamplerIndex", "base"), ("m_NormalTextureIndex", "m_NormalSamplerIndex", "normal"),
+                                ("m_RoughnessMetallicTextureIndex", "m_RoughnessSamplerIndex", "mr"), ("m_EmissiveTextureIndex", "m_EmissiveSamplerIndex", "emissive")):
+            g[smp] = textures[refs[key]]["sampler"] if refs[key] != -1 else 1
+            if refs[key] != -1:
+                g[field] = textures[refs[key]]["bindless"]
+        out_mats[i] = g
+    # light buffer
+    gpu_lights = np.zeros(len(lights), GPULight)
+    for i, l in enumerate(lights):
+        w = nodes[l["node"]]["world"]
+        gl = gpu_lights[i]
+        gl["m_Type"] = l["type"]; gl["m_Color"] = l["color"]; gl["m_Intensity"] = l["intensity"]; gl["m_Range"] = l["range"]; gl["m_Radius"] = l["radius"]
+        gl["m_SpotInnerConeAngle"] = l["inner"]; gl["m_SpotOuterConeAngle"] = l["outer"]; gl["m_CosSunAngularRadius"] = 1.0
+        gl["m_Position"] = w[3, :3]; gl["m_Direction"] = normalize3(w[2, :3])
+        if l["type"] == LIGHT_DIRECTIONAL:
+            gl["m_CosSunAngularRadius"] = f32(math.cos(float(f32(f32(f32(l["angular"]) * f32(0.5)) * f32(f32(3.141592654) / f32(180.0))))))
+    sun_node = nodes[lights[-1]["node"]]["world"]
+    sun = normalize3(transform_normal(np.array([0, 0, -1], np.float32), sun_node))
+    camera = {"position": np.array([0, 0, -5], np.float32), "yaw": f32(0), "pitch": f32(0), "fovY": f32(0.785398163), "aspect": f32(16.0) / f32(9.0), "nearZ": f32(0.1)}
+    if cameras and cameras[0]["node"] >= 0:
+        w = nodes[cameras[0]["node"]]["world"]
+        fwd = normalize3(transform_normal(np.array([0, 0, 1], np.float32), w))
+        camera = {"position": w[3, :3].copy(), "yaw": f32(math.atan2(float(fwd[0]), float(fwd[2]))), "pitch": f32(-math.asin(float(fwd[1]))),
+                  "fovY": cameras[0]["fovY"], "aspect": cameras[0]["aspect"], "nearZ": cameras[0]["nearZ"]}
+    return {"vertices": np.concatenate(vertices) if vertices else np.zeros(0, VertexQuantized),
+            "indices": np.concatenate(indices).astype(np.uint32) if indices else np.zeros(0, np.uint32),
+            "mesh_data": np.array(mesh_data, MeshData) if mesh_data else np.zeros(0, MeshData), "instances": instances, "materials": out_mats,
+            "lights": gpu_lights, "textures": textures, "sun_direction": sun, "camera": camera, "camera_count": len(cameras)}

@@ -1,0 +1,247 @@
+"""Synthetic glTF 2.0 assets for the ingestion tests: written from scratch here (no asset ships with the reference)."""
+import base64
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+
+
+def write_png(path, pixels, color_type, depth=8, interlace=False, palette=None, trns=None, filters=None):
+    """pixels: (H, W, C) integer samples in file precision. filters: per-row filter types (default: cycles 0..4)."""
+    h, w, c = pixels.shape
+    bits = c * depth
+
+    def pack_rows(img):
+        rows = []
+        for y in range(img.shape[0]):
+            s = img[y].reshape(-1)
+            if depth == 8:
+                rows.append(s.astype(np.uint8).tobytes())
+            elif depth == 16:
+                rows.append(s.astype(">u2").tobytes())
+            else:
+                b = np.zeros(len(s) * depth, np.uint8)
+                for k in range(depth):
+                    b[k::depth] = (s >> (depth - 1 - k)) & 1
+                rows.append(np.packbits(b).tobytes())
+        return rows
+
+    def filt(rows, bpp):
+        out, prev = b"", None
+        for y, raw in enumerate(rows):
+            ft = (filters[y % len(filters)] if filters else y % 5)
+            cur = np.frombuffer(raw, np.uint8).astype(np.int32)
+            up = np.frombuffer(prev, np.uint8).astype(np.int32) if prev is not None else np.zeros_like(cur)
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            ul = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = left
+            elif ft == 2:
+                pred = up
+            elif ft == 3:
+                pred = (left + up) >> 1
+            else:
+                p = left + up - ul
+                pa, pb, pc = abs(p - left), abs(p - up), abs(p - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
+            out += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+            prev = raw
+        return out
+
+    bpp = max(1, bits // 8)
+    if not interlace:
+        raw = filt(pack_rows(pixels), bpp)
+    else:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = pixels[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filt(pack_rows(sub), bpp)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        data += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(raw, 6)
+    half = len(comp) // 2
+    data += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")   # split IDAT on purpose
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+class Asset:
+    """Accumulates buffers / accessors and writes .gltf (+ .bin or data URI) or .glb."""
+
+    def __init__(self):
+        self.bin = bytearray()
+        self.j = {"asset": {"version": "2.0"}, "bufferViews": [], "accessors": [], "meshes": [], "nodes": [], "materials": [], "scenes": [{"nodes": []}], "scene": 0}
+
+    def add_accessor(self, array, comp_type, gltf_type, normalized=False, stride=None):
+        arr = np.ascontiguousarray(array)
+        while len(self.bin) % 4:
+            self.bin.append(0)
+        off = len(self.bin)
+        n = arr.shape[0]
+        if stride:
+            row = arr.reshape(n, -1)
+            rb = row.dtype.itemsize * row.shape[1]
+            for i in range(n):
+                self.bin += row[i].tobytes() + b"\xAB" * (stride - rb)
+        else:
+            self.bin += arr.tobytes()
+        view = {"buffer": 0, "byteOffset": off, "byteLength": len(self.bin) - off}
+        if stride:
+            view["byteStride"] = stride
+        self.j["bufferViews"].append(view)
+        acc = {"bufferView": len(self.j["bufferViews"]) - 1, "componentType": comp_type, "count": n, "type": gltf_type}
+        if normalized:
+            acc["normalized"] = True
+        self.j["accessors"].append(acc)
+        return len(self.j["accessors"]) - 1
+
+    def add_primitive(self, mesh, pos, idx=None, nrm=None, uv=None, tan=None, material=None, idx_type=5125, uv_norm16=False, nrm_norm8=False, stride_pos=None):
+        attrs = {"POSITION": self.add_accessor(np.asarray(pos, "<f4"), 5126, "VEC3", stride=stride_pos)}
+        if nrm is not None:
+            if nrm_norm8:
+                q = np.clip(np.round(np.asarray(nrm, np.float64) * 127), -127, 127).astype("i1")
+                q4 = np.zeros((len(q), 4), "i1"); q4[:, :3] = q            # 4-byte aligned rows via byteStride
+                attrs["NORMAL"] = self.add_accessor(q4[:, :3].copy(), 5120, "VEC3", normalized=True, stride=4)
+            else:
+                attrs["NORMAL"] = self.add_accessor(np.asarray(nrm, "<f4"), 5126, "VEC3")
+        if uv is not None:
+            if uv_norm16:
+                attrs["TEXCOORD_0"] = self.add_accessor(np.clip(np.round(np.asarray(uv, np.float64) * 65535), 0, 65535).astype("<u2"), 5123, "VEC2", normalized=True)
+            else:
+                attrs["TEXCOORD_0"] = self.add_accessor(np.asarray(uv, "<f4"), 5126, "VEC2")
+        if tan is not None:
+            attrs["TANGENT"] = self.add_accessor(np.asarray(tan, "<f4"), 5126, "VEC4")
+        p = {"attributes": attrs}
+        if idx is not None:
+            dt = {5121: "u1", 5123: "<u2", 5125: "<u4"}[idx_type]
+            p["indices"] = self.add_accessor(np.asarray(idx, dt).reshape(-1), idx_type, "SCALAR")
+        if material is not None:
+            p["material"] = material
+        while len(self.j["meshes"]) <= mesh:
+            self.j["meshes"].append({"primitives": []})
+        self.j["meshes"][mesh]["primitives"].append(p)
+
+    def write(self, path, mode="bin"):
+        j = json.loads(json.dumps(self.j))
+        j["buffers"] = [{"byteLength": len(self.bin)}]
+        if mode == "glb":
+            js = json.dumps(j).encode()
+            js += b" " * ((4 - len(js) % 4) % 4)
+            b = bytes(self.bin) + b"\0" * ((4 - len(self.bin) % 4) % 4)
+            with open(path, "wb") as f:
+                f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(b)))
+                f.write(struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(b), 0x004E4942) + b)
+            return
+        if mode == "datauri":
+            j["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(bytes(self.bin)).decode()
+        else:
+            name = os.path.splitext(os.path.basename(path))[0] + " data.bin"      # a space: exercises percent-decoding
+            j["buffers"][0]["uri"] = name.replace(" ", "%20")
+            with open(os.path.join(os.path.dirname(path), name), "wb") as f:
+                f.write(bytes(self.bin))
+        with open(path, "w") as f:
+            json.dump(j, f, indent=1)
+
+
+def grid(nx, ny, size=1.0, z=0.0, seed=0, jitter=0.0):
+    """(nx+1)*(ny+1) vertex grid in the XY plane: positions, normals (+Z in glTF's RH space), uvs, CCW indices."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.linspace(-size, size, nx + 1), np.linspace(-size, size, ny + 1))
+    pos = np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, z)], 1).astype(np.float32)
+    pos[:, 2] += (rng.random(len(pos)) * jitter).astype(np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (len(pos), 1))
+    uv = np.stack([(xs.ravel() + size) / (2 * size), (ys.ravel() + size) / (2 * size)], 1).astype(np.float32)
+    idx = []
+    for y in range(ny):
+        for x in range(nx):
+            a = y * (nx + 1) + x
+            idx += [a, a + 1, a + nx + 2, a, a + nx + 2, a + nx + 1]
+    return pos, nrm, uv, np.array(idx, np.uint32)
+
+
+def build_showcase(dirpath, mode="bin", name="showcase"):
+    """One asset touching every ingestion rule: three meshes, TRS + matrix nodes with a parent chain, all material extensions,
+    MASK/BLEND, the three light types in file order directional-first, two cameras (one orthographic), PNG textures of several colour
+    types, a texture with a CLAMP sampler, normalised attributes, u8/u16/u32 indices, a primitive without indices / normals, degenerate and
+    duplicate triangles."""
+    os.makedirs(dirpath, exist_ok=True)
+    rng = np.random.default_rng(7)
+    tex = (rng.integers(0, 256, (8, 8, 4))).astype(np.uint16)
+    write_png(os.path.join(dirpath, "albedo rgba.png"), tex, 6)
+    write_png(os.path.join(dirpath, "normal.png"), np.concatenate([rng.integers(96, 160, (4, 4, 2)), np.full((4, 4, 1), 255)], 2).astype(np.uint16), 2)
+    write_png(os.path.join(dirpath, "orm16.png"), (rng.integers(0, 65536, (4, 8, 3))).astype(np.uint16), 2, depth=16, interlace=True)
+    write_png(os.path.join(dirpath, "emissive_pal.png"), rng.integers(0, 4, (5, 7, 1)).astype(np.uint16), 3, depth=2, palette=[[255, 0, 0], [0, 255, 0], [0, 0, 255], [9, 9, 9]], trns=[255, 128])
+    a = Asset()
+    j = a.j
+    j["images"] = [{"uri": "albedo%20rgba.png"}, {"uri": "normal.png"}, {"uri": "orm16.png"}, {"uri": "emissive_pal.png"}, {"uri": "missing.png"}]
+    j["samplers"] = [{"wrapS": 33071, "wrapT": 33071}, {"wrapS": 33071, "wrapT": 10497}]
+    j["textures"] = [{"source": 0}, {"source": 1, "sampler": 0}, {"source": 2, "sampler": 1}, {"source": 3}, {"source": 4}]
+    j["materials"] = [
+        {"name": "textured", "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 0.7, 1.0], "baseColorTexture": {"index": 0}, "metallicFactor": 1.0, "roughnessFactor": 0.6,
+                                                      "metallicRoughnessTexture": {"index": 2}}, "normalTexture": {"index": 1}, "emissiveTexture": {"index": 3}, "emissiveFactor": [0.5, 0.25, 0.125],
+         "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}}},
+        {"name": "metal_no_tex", "pbrMetallicRoughness": {"metallicFactor": 1.0, "roughnessFactor": 0.3}},       # metallic 1 without a texture -> 0
+        {"name": "mask", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.9, 0.3, 0.4]}, "alphaMode": "MASK", "alphaCutoff": 0.35},
+        {"name": "blend", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.3, 0.9, 0.5], "metallicFactor": 0.0}, "alphaMode": "BLEND"},
+        {"name": "glass", "pbrMetallicRoughness": {"metallicFactor": 0.0, "roughnessFactor": 0.05},
+         "extensions": {"KHR_materials_transmission": {"transmissionFactor": 0.9}, "KHR_materials_ior": {"ior": 1.33},
+                        "KHR_materials_volume": {"thicknessFactor": 0.5, "attenuationDistance": 0.5, "attenuationColor": [0.5, 0.25, 1.0]}}},
+        {"name": "thin", "extensions": {"KHR_materials_transmission": {"transmissionFactor": 1.0}, "KHR_materials_volume": {"thicknessFactor": 0.0}}},
+        {"name": "specgloss", "extensions": {"KHR_materials_pbrSpecularGlossiness": {"diffuseFactor": [0.4, 0.5, 0.6, 1.0], "specularFactor": [0.1, 0.7, 0.2], "glossinessFactor": 0.25,
+                                                                                       "diffuseTexture": {"index": 0}}}},
+        {"name": "bare"},
+        {"name": "missing_tex", "pbrMetallicRoughness": {"baseColorTexture": {"index": 4}}},
+    ]
+    # mesh 0: textured grid (no tangents -> generated), u16 indices, normalised uv / normal
+    p, n, uv, i = grid(5, 4, 1.0, 0.0, 1, 0.2)
+    a.add_primitive(0, p, i, n, uv, material=0, idx_type=5123, uv_norm16=True, nrm_norm8=True, stride_pos=16)
+    # mesh 0, second primitive: explicit tangents, u32 indices, with degenerate + duplicate triangles appended
+    p, n, uv, i = grid(3, 3, 0.6, 0.5, 2)
+    tan = np.tile(np.array([1, 0, 0, 1], np.float32), (len(p), 1))
+    i = np.concatenate([i, [0, 0, 1], i[:3], [i[1], i[2], i[0]]]).astype(np.uint32)
+    a.add_primitive(0, p, i, n, uv, tan, material=6)
+    # mesh 1: no indices, no normals, u8-free: triangle soup + masked material
+    soup = (rng.random((12, 3)).astype(np.float32) - 0.5)
+    a.add_primitive(1, soup, None, None, None, material=2)
+    # mesh 1 second primitive: u8 indices, blend
+    p, n, uv, i = grid(2, 2, 0.4, -0.3, 3)
+    a.add_primitive(1, p, i, n, uv, material=3, idx_type=5121)
+    # mesh 2: glass slab (two grids), thin pane, bare and metal
+    for k, m in enumerate((4, 5, 7, 1, 8)):
+        p, n, uv, i = grid(2, 1, 0.3, 0.1 * k, 4 + k)
+        a.add_primitive(2, p, i, n, uv, material=m)
+    j["cameras"] = [{"type": "orthographic", "orthographic": {"xmag": 1, "ymag": 1, "zfar": 10, "znear": 0.1}},
+                    {"type": "perspective", "perspective": {"yfov": 0.7, "znear": 0.05, "aspectRatio": 1.5}}, {"type": "perspective", "perspective": {"yfov": 0.5, "znear": 0.2}}]
+    j["extensionsUsed"] = ["KHR_lights_punctual", "KHR_materials_transmission"]
+    j["extensions"] = {"KHR_lights_punctual": {"lights": [
+        {"type": "directional", "color": [1.0, 0.9, 0.8], "intensity": 2.0},
+        {"type": "point", "color": [0.2, 0.4, 1.0], "intensity": 30.0, "range": 9.0},
+        {"type": "spot", "intensity": 50.0, "spot": {"innerConeAngle": 0.2, "outerConeAngle": 0.5}}]}}
+    s = 0.5 ** 0.5
+    j["nodes"] = [
+        {"name": "root", "children": [1, 2], "translation": [0.1, 0.2, 0.3], "rotation": [0.0, s, 0.0, s], "scale": [1.0, 2.0, 1.0]},
+        {"name": "child_mesh0", "mesh": 0, "translation": [1.0, 0.0, -2.0]},
+        {"name": "child_matrix", "mesh": 1, "children": [3], "matrix": [0.0, 0.0, -1.5, 0.0, 0.0, 1.5, 0.0, 0.0, 1.5, 0.0, 0.0, 0.0, 0.5, -0.25, 4.0, 1.0]},
+        {"name": "grandchild", "mesh": 2, "rotation": [0.3826834, 0.0, 0.0, 0.9238795], "scale": [-1.0, 1.0, 1.0]},
+        {"name": "mesh0_again", "mesh": 0, "translation": [-2.0, 1.0, 1.0], "scale": [0.5, 0.5, 0.5]},
+        {"name": "cam_ortho", "camera": 0}, {"name": "cam", "camera": 1, "translation": [0.0, 1.0, 6.0], "rotation": [-0.0871557, 0.0, 0.0, 0.9961947]},
+        {"name": "sun", "extensions": {"KHR_lights_punctual": {"light": 0}}, "rotation": [-0.5, 0.0, 0.0, 0.8660254]},
+        {"name": "bulb", "extensions": {"KHR_lights_punctual": {"light": 1}}, "translation": [0.5, 2.0, 0.5]},
+        {"name": "torch", "extensions": {"KHR_lights_punctual": {"light": 2}}, "translation": [-1.0, 3.0, 1.0], "rotation": [-s, 0.0, 0.0, s]},
+    ]
+    j["scenes"][0]["nodes"] = [0, 4, 5, 6, 7, 8, 9]
+    path = os.path.join(dirpath, name + (".glb" if mode == "glb" else ".gltf"))
+    a.write(path, mode)
+    return path

@@ -55,3 +55,29 @@ def test_plugin_path_equals_oracle(tmp_path, luts, scene, w, h, frames, bounces)
     oacc, oout = o.render_accumulated(lambda i: scenes.fill_constants(d["view"], d["misc"][3:6], sc, i, bounces, frame_index=i), w, h, frames)
     assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
     assert np.array_equal(out.view(np.uint32), oout.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_plugin_path_on_a_gltf_scene_equals_oracle(tmp_path, luts):
+    """C++ route end to end: SceneLoader::LoadSceneFile (glTF + textures + cooked-mesh cache) -> Scene -> PathTracerRenderer::Render
+    -> C ABI, against the oracle on the arrays the same loader hands out through hrsc_scene_view."""
+    from gltf_helpers import build_showcase
+    from hobbyrenderer_amd import scene_io
+    from oracle.binding import Oracle
+    path = build_showcase(str(tmp_path))
+    w, h, frames, bounces = 80, 48, 2, 4
+    prefix = str(tmp_path / "g")
+    for extra in ((), ("--mesh-cache",), ("--mesh-cache",)):        # plain, cooking the cache, reading the cache
+        subprocess.check_call([DEMO, "--gltf", path, "--width", str(w), "--height", str(h), "--frames", str(frames), "--bounces", str(bounces), "--dump", "--out", prefix, *extra])
+        loaded = scene_io.load_gltf(path, luts)
+        sc = loaded.arrays
+        assert np.fromfile(prefix + "_vertices.bin", S.VertexQuantized).tobytes() == sc.vertices.tobytes()
+        assert np.fromfile(prefix + "_instances.bin", S.PerInstanceData).tobytes() == sc.instances.tobytes()
+        assert np.fromfile(prefix + "_materials.bin", S.MaterialConstants).tobytes() == sc.materials.tobytes()
+        view = np.fromfile(prefix + "_view.bin", S.PlanarViewConstants)[0]
+        misc = np.fromfile(prefix + "_misc.bin", np.float32)
+        acc = np.fromfile(prefix + "_accumulation.bin", np.float32).reshape(h, w, 4)
+        o = Oracle(sc)
+        oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, misc[3:6], sc, i, bounces, frame_index=i), w, h, frames)
+        assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+    assert (tmp_path / "showcase_mesh.bin").exists()
