@@ -179,11 +179,15 @@ struct GlobalBvh4 {
 // reported (the hit definition is BVH-independent), so it may use native min/max, the hardware reciprocal and
 // FMA. A NaN plane distance (zero direction component with the origin exactly on a padded slab plane) culls the
 // box, which is still conservative: padded planes lie strictly outside every triangle extent inside the box.
-HRT_DEV bool slab(float4 bmin, float4 bmax, f3 o, f3 inv, float t0, float t1, float& tnear)
+// Plane distances are one FMA each: t = plane * inv + noi with noi = -(o * inv) computed once per ray. Its error,
+// ~6e-8 * |o * inv|, is covered either by the 2e-6 relative widening (when the plane is far from the origin compared with |o|)
+// or by the box padding 1e-5 * |coord| + 1e-6 (when it is not). inv is finite (traversal_rcp caps it), so no NaN arises.
+HRT_DEV f3 slab_origin_term(f3 o, f3 inv) { return mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); }
+HRT_DEV bool slab(float4 bmin, float4 bmax, f3 noi, f3 inv, float t0, float t1, float& tnear)
 {
-    float tx0 = (bmin.x - o.x) * inv.x, tx1 = (bmax.x - o.x) * inv.x;
-    float ty0 = (bmin.y - o.y) * inv.y, ty1 = (bmax.y - o.y) * inv.y;
-    float tz0 = (bmin.z - o.z) * inv.z, tz1 = (bmax.z - o.z) * inv.z;
+    float tx0 = __builtin_fmaf(bmin.x, inv.x, noi.x), tx1 = __builtin_fmaf(bmax.x, inv.x, noi.x);
+    float ty0 = __builtin_fmaf(bmin.y, inv.y, noi.y), ty1 = __builtin_fmaf(bmax.y, inv.y, noi.y);
+    float tz0 = __builtin_fmaf(bmin.z, inv.z, noi.z), tz1 = __builtin_fmaf(bmax.z, inv.z, noi.z);
     float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), t0));
     float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fminf(__builtin_fmaxf(tz0, tz1), t1));
     tnear = lo;
@@ -194,11 +198,11 @@ HRT_DEV bool slab(float4 bmin, float4 bmax, f3 o, f3 inv, float t0, float t1, fl
 constexpr int32_t kTraversalDone = (int32_t)0x80000000;   // not a valid leaf encoding (first < 2^29)
 
 // one box of a 4-wide node: entry distance, or +inf on a miss
-HRT_DEV float slab1(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 o, f3 inv, float t0, float t1)
+HRT_DEV float slab1(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 noi, f3 inv, float t0, float t1)
 {
-    float tx0 = (bminx - o.x) * inv.x, tx1 = (bmaxx - o.x) * inv.x;
-    float ty0 = (bminy - o.y) * inv.y, ty1 = (bmaxy - o.y) * inv.y;
-    float tz0 = (bminz - o.z) * inv.z, tz1 = (bmaxz - o.z) * inv.z;
+    float tx0 = __builtin_fmaf(bminx, inv.x, noi.x), tx1 = __builtin_fmaf(bmaxx, inv.x, noi.x);
+    float ty0 = __builtin_fmaf(bminy, inv.y, noi.y), ty1 = __builtin_fmaf(bmaxy, inv.y, noi.y);
+    float tz0 = __builtin_fmaf(bminz, inv.z, noi.z), tz1 = __builtin_fmaf(bmaxz, inv.z, noi.z);
     float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), t0));
     float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fminf(__builtin_fmaxf(tz0, tz1), t1));
     bool hit = __builtin_fmaf(-__builtin_fabsf(lo), 2e-6f, lo) <= __builtin_fmaf(__builtin_fabsf(hi), 2e-6f, hi);
@@ -214,14 +218,14 @@ HRT_DEV void cswap(float& ta, int32_t& ra, float& tb, int32_t& rb)
 // One traversal step from inner node `cur`: tests its child boxes against [tmin, tlim], pushes the far hits (nearest on
 // top) and returns the next node reference: the nearest hit child, else the popped stack top, else kTraversalDone.
 template <class BVH, class STACK>
-HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 o, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
+HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
 {
     if constexpr (BVH::kWidth == 2) {
         float4 a, b, c, d; bvh.node(cur, a, b, c, d);
         int32_t li = __float_as_int(a.w), ri = __float_as_int(b.w);
         float tl, tr;
-        bool hl = slab(a, b, o, inv, tmin, tlim, tl);
-        bool hr = slab(c, d, o, inv, tmin, tlim, tr);
+        bool hl = slab(a, b, noi, inv, tmin, tlim, tl);
+        bool hr = slab(c, d, noi, inv, tmin, tlim, tr);
         if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); return leftFirst ? li : ri; }
         if (hl) return li;
         if (hr) return ri;
@@ -229,10 +233,10 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 o, f3 inv, float tmin
     } else {
         float4 mnx, mny, mnz, mxx, mxy, mxz; int4 ch;
         bvh.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, ch);
-        float t0 = slab1(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, inv, tmin, tlim);
-        float t1 = slab1(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, inv, tmin, tlim);
-        float t2 = slab1(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, inv, tmin, tlim);
-        float t3 = slab1(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, inv, tmin, tlim);
+        float t0 = slab1(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, noi, inv, tmin, tlim);
+        float t1 = slab1(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, noi, inv, tmin, tlim);
+        float t2 = slab1(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, noi, inv, tmin, tlim);
+        float t3 = slab1(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, noi, inv, tmin, tlim);
         int32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
         cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
         const float inf = __builtin_inff();
@@ -246,7 +250,11 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 o, f3 inv, float tmin
 
 HRT_DEV f3 traversal_rcp(f3 d)
 {
-    return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // |1/d| is capped at 1e20 (a zero component would give inf, and inf * plane - inf * origin is NaN in the FMA slab form): over
+    // t <= 1e10 such a ray moves less than 1e-10 along that axis, far inside the 1e-6 box padding, so the capped interval still
+    // contains every t at which the ray is inside the box.
+    auto one = [](float x) { return __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(x), -1e20f), 1e20f); };
+    return mk3(one(d.x), one(d.y), one(d.z));
 }
 
 // Closest triangle (opaque or not) with key strictly above `lower` (when lower.have) in (t, inst, prim) order.
@@ -258,14 +266,14 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0; best.tri = 0;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
     RayShear sh = make_shear(r.d);
-    f3 inv = traversal_rcp(r.d);
+    f3 inv = traversal_rcp(r.d), noi = slab_origin_term(r.o, inv);
     int sp = 0;
     int32_t cur;                       // current node reference: >= 0 inner, < 0 leaf
     if (nodeCount == 0) { if (rootLeaf == 0) return best; cur = rootLeaf; }
     else cur = 0;
     float tlim = r.tmax;               // == best.t once a hit exists
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
+        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, r.tmin, tlim, stack, sp);
         if (cur == kTraversalDone) break;
         {
             uint32_t enc = (uint32_t)(~cur);
@@ -297,12 +305,12 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     sawNonOpaque = false;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
     RayShear sh = make_shear(r.d);
-    f3 inv = traversal_rcp(r.d);
+    f3 inv = traversal_rcp(r.d), noi = slab_origin_term(r.o, inv);
     int sp = 0; int32_t cur;
     if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
     else cur = 0;
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, r.o, inv, r.tmin, r.tmax, stack, sp);
+        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, r.tmin, r.tmax, stack, sp);
         if (cur == kTraversalDone) break;
         {
             uint32_t enc = (uint32_t)(~cur);

@@ -156,12 +156,12 @@ HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 world
     Ray ray = shadow_ray(worldPos, L, maxDist);
     if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
     RayShear sh = make_shear(ray.d);
-    f3 inv = traversal_rcp(ray.d);
+    f3 inv = traversal_rcp(ray.d), noi = slab_origin_term(ray.o, inv);
     int sp = 0, count = 0; bool overflow = false;
     int32_t cur;
     if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, ray.o, inv, ray.tmin, ray.tmax, stack, sp);
+        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, ray.tmin, ray.tmax, stack, sp);
         if (cur == kTraversalDone) break;
         uint32_t enc = (uint32_t)(~cur);
         uint32_t first = enc >> 2, n = (enc & 3u) + 1u;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
         // per-lane traversal state
         bool active = false;
         Ray r; r.o = mk3(0.0f, 0.0f, 0.0f); r.d = mk3(0.0f, 0.0f, 1.0f); r.tmin = 0.0f; r.tmax = 1e10f;
-        RayShear sh = make_shear(r.d); f3 inv = mk3(0.0f, 0.0f, 0.0f);
+        RayShear sh = make_shear(r.d); f3 inv = mk3(0.0f, 0.0f, 0.0f), noi = mk3(0.0f, 0.0f, 0.0f);
         HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
         Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
         int32_t cur = kTraversalDone; int sp = 0; uint32_t slot = 0, rng = 0, rng0 = 0; float tlim = 0.0f;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                     lower.have = false;
                     best.valid = false; tlim = r.tmax; sp = 0;
                     bool finite = (r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z);
-                    sh = make_shear(r.d); inv = traversal_rcp(r.d);
+                    sh = make_shear(r.d); inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv);
                     cur = (emptyScene || !finite) ? kTraversalDone : (s.nodeCount == 0 ? s.rootLeaf : 0);
                     active = true; ++nRays;
                 }
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             if (active) {
                 // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
                 while (cur >= 0) {
-                    if (LDS_BVH) cur = inner_step(lbvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
-                    else cur = inner_step(gbvh, cur, r.o, inv, r.tmin, tlim, stack, sp);
+                    if (LDS_BVH) cur = inner_step(lbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+                    else cur = inner_step(gbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
                 }
                 // ---- intersect the leaf
                 if (cur != kTraversalDone) {
