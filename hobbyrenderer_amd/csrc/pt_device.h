@@ -645,27 +645,30 @@ HRT_DEV void tangent_frame(f3 N, f3& T, f3& B)                                //
     B = cross(N, T);
 }
 HRT_DEV f3 frame_combine(f3 T, f3 N, f3 B, f3 l) { return (T * l.x + N * l.y) + B * l.z; }
-HRT_DEV f3 sample_hemisphere_cosine(float ux, float uy, f3 normal)            // :170-183
+// The two BRDF lobes share their first steps -- two random numbers, sin/cos of 2*pi*u, one square root, the tangent frame of N --
+// so the callers evaluate those once (shade_surface_b) and the lobes start from them: `root` = sqrt(uy) (cosine) or sqrt(ux) (VNDF),
+// (sp, cp) = sincos(2*pi*ux) (cosine) or sincos(2*pi*uy) (VNDF). Same operations on the same values as the reference order.
+HRT_DEV f3 sample_hemisphere_cosine_from(float root, float sp, float cp, f3 T, f3 B, f3 normal)   // :170-183
 {
-    float phi = 2.0f * HRT_PI * ux;
-    float cosTheta = hrt_sqrt(uy);
+    float cosTheta = root;
     float sinTheta = hrt_sqrt(hrt_max(0.0f, 1.0f - cosTheta * cosTheta));
-    float sp, cp; hrt_sincos(phi, &sp, &cp);
-    f3 T, B; tangent_frame(normal, T, B);
     return frame_combine(T, normal, B, mk3(sinTheta * cp, cosTheta, sinTheta * sp));
 }
-HRT_DEV f3 sample_ggx_vndf(float ux, float uy, f3 N, f3 V, float roughness)   // :622-655
+HRT_DEV f3 sample_hemisphere_cosine(float ux, float uy, f3 normal)
+{
+    float sp, cp; hrt_sincos(2.0f * HRT_PI * ux, &sp, &cp);
+    f3 T, B; tangent_frame(normal, T, B);
+    return sample_hemisphere_cosine_from(hrt_sqrt(uy), sp, cp, T, B, normal);
+}
+HRT_DEV f3 sample_ggx_vndf_from(float root, float sp, float cp, f3 T, f3 B, f3 N, f3 V, float roughness)   // :622-655
 {
     float alpha = roughness * roughness;
-    f3 T, B; tangent_frame(N, T, B);
     f3 Vl = mk3(dot(V, T), dot(V, N), dot(V, B));
     f3 Vh = normalize(mk3(alpha * Vl.x, Vl.y, alpha * Vl.z));
     float lensq = Vh.x * Vh.x + Vh.z * Vh.z;
     f3 T1 = lensq > 0.0f ? mk3(-Vh.z, 0.0f, Vh.x) / hrt_sqrt(lensq) : mk3(1.0f, 0.0f, 0.0f);
     f3 T2 = cross(Vh, T1);
-    float r = hrt_sqrt(ux);
-    float phi = 2.0f * HRT_PI * uy;
-    float sp, cp; hrt_sincos(phi, &sp, &cp);
+    float r = root;
     float t1 = r * cp, t2 = r * sp;
     float s = 0.5f * (1.0f + Vh.y);
     t2 = lerp(hrt_sqrt(hrt_max(0.0f, 1.0f - t1 * t1)), t2, s);
@@ -673,6 +676,12 @@ HRT_DEV f3 sample_ggx_vndf(float ux, float uy, f3 N, f3 V, float roughness)   //
     f3 Nh = (T1 * t1 + T2 * t2) + Vh * nz;
     f3 Ne = normalize(mk3(alpha * Nh.x, hrt_max(0.0f, Nh.y), alpha * Nh.z));
     return frame_combine(T, N, B, Ne);
+}
+HRT_DEV f3 sample_ggx_vndf(float ux, float uy, f3 N, f3 V, float roughness)
+{
+    float sp, cp; hrt_sincos(2.0f * HRT_PI * uy, &sp, &cp);
+    f3 T, B; tangent_frame(N, T, B);
+    return sample_ggx_vndf_from(hrt_sqrt(ux), sp, cp, T, B, N, V, roughness);
 }
 HRT_DEV f3 eval_ggx_vndf_weight(f3 F0, f3 N, f3 V, f3 L, f3 H, float roughness)   // :671-688
 {

@@ -416,19 +416,25 @@ HRT_DEV bool shade_surface_b(PathState& ps, const SurfaceCarry& c, int bounce)
         ps.throughput = ps.throughput / continuePr;
     }
     float specProb = hrt_clamp(lerp(c.Fr * 0.5f + 0.5f * c.metallic, 1.0f, c.metallic), 0.1f, 0.9f);   // :275
-    f3 newDir, brdfWeight;
-    if (hrt_rng_next(&ps.rng) < specProb) {
-        float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
-        f3 H = sample_ggx_vndf(ux, uy, c.N, c.V, c.roughness);
+    // lobe pick, then the work both lobes share (two draws, one sincos, one sqrt, the tangent frame, the final division) is done
+    // once for the whole wave instead of once per divergent branch; values and operation order per path are unchanged
+    const bool spec = hrt_rng_next(&ps.rng) < specProb;
+    const float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
+    float sp, cp; hrt_sincos(2.0f * HRT_PI * (spec ? uy : ux), &sp, &cp);
+    const float root = hrt_sqrt(spec ? ux : uy);
+    f3 T, B; tangent_frame(c.N, T, B);
+    f3 newDir, numer;
+    if (spec) {
+        f3 H = sample_ggx_vndf_from(root, sp, cp, T, B, c.N, c.V, c.roughness);
         newDir = reflect(-c.V, H);
         if (dot(c.N, newDir) <= 0.0f) return false;
-        brdfWeight = eval_ggx_vndf_weight(c.F0, c.N, c.V, newDir, H, c.roughness) / specProb;
+        numer = eval_ggx_vndf_weight(c.F0, c.N, c.V, newDir, H, c.roughness);
     } else {
-        float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
-        newDir = sample_hemisphere_cosine(ux, uy, c.N);
+        newDir = sample_hemisphere_cosine_from(root, sp, cp, T, B, c.N);
         if (dot(c.N, newDir) <= 0.0f) return false;
-        brdfWeight = (c.baseColor * (1.0f - c.metallic)) / (1.0f - specProb);
+        numer = c.baseColor * (1.0f - c.metallic);
     }
+    f3 brdfWeight = numer / (spec ? specProb : 1.0f - specProb);
     ps.throughput = ps.throughput * brdfWeight;
     if (maxcomp(ps.throughput) < 0.01f) return false;                             // :306
     ps.ray.o = c.worldPos; ps.ray.d = newDir; ps.ray.tmin = 1e-4f; ps.ray.tmax = 1e10f;   // :310-313
