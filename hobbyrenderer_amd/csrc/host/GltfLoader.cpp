@@ -94,7 +94,8 @@ struct Document {
         for (size_t i = 0; i < arr.size(); ++i) {
             const json::Value& b = arr[i];
             const json::Value* uri = b.find("uri");
-            size_t want = (size_t)b["byteLength"].i64(0);
+            size_t want = 0;
+            if (!field(b, "byteLength", 0, want)) return fail("glTF buffer " + std::to_string(i) + ": bad byteLength");
             if (!uri) {
                 if (i != 0 || !glbBin) return fail("glTF buffer " + std::to_string(i) + " has no uri and there is no GLB BIN chunk");
                 buffers[i] = *glbBin;
@@ -111,6 +112,16 @@ struct Document {
         return true;
     }
 
+    // non-negative integer field (offsets, lengths, counts, indices); absent -> dflt; negative / fractional / enormous -> error
+    static bool field(const json::Value& obj, const char* key, size_t dflt, size_t& out)
+    {
+        const json::Value* v = obj.find(key);
+        if (!v) { out = dflt; return true; }
+        if (!v->is(json::Value::Number) || !v->isInteger || v->integer < 0 || v->integer > (int64_t)1 << 40) return false;
+        out = (size_t)v->integer;
+        return true;
+    }
+
     bool resolve_accessors()
     {
         const json::Value& arr = root["accessors"]; const json::Value& views = root["bufferViews"];
@@ -118,15 +129,20 @@ struct Document {
         for (size_t i = 0; i < arr.size(); ++i) {
             const json::Value& a = arr[i]; Accessor& acc = accessors[i];
             if (a.find("sparse")) return fail("sparse accessors are not supported (accessor " + std::to_string(i) + ")");
-            acc.bufferView = (int)a["bufferView"].i64(-1); acc.byteOffset = (size_t)a["byteOffset"].i64(0); acc.componentType = (int)a["componentType"].i64(0);
-            acc.normalized = a["normalized"].flag(false); acc.count = (size_t)a["count"].i64(0); acc.components = type_components(a["type"].str(""));
+            size_t viewIndex = 0;
+            if (!field(a, "byteOffset", 0, acc.byteOffset) || !field(a, "count", 0, acc.count) || !field(a, "bufferView", ~(size_t)0 >> 24, viewIndex))
+                return fail("accessor " + std::to_string(i) + ": byteOffset / count / bufferView must be non-negative integers");
+            acc.bufferView = a.find("bufferView") ? (int)std::min<size_t>(viewIndex, 0x7fffffff) : -1; acc.componentType = (int)a["componentType"].i64(0);
+            acc.normalized = a["normalized"].flag(false); acc.components = type_components(a["type"].str(""));
             int cs = component_size(acc.componentType);
             if (!cs || !acc.components) return fail("accessor " + std::to_string(i) + ": bad componentType / type");
             if (acc.bufferView < 0) { acc.base = nullptr; continue; }          // all zeros per the specification
             if ((size_t)acc.bufferView >= views.size()) return fail("accessor " + std::to_string(i) + ": bufferView out of range");
             const json::Value& v = views[(size_t)acc.bufferView];
             if (v["extensions"].find("EXT_meshopt_compression")) return fail("EXT_meshopt_compression buffer views are not supported");
-            size_t buf = (size_t)v["buffer"].i64(-1), vo = (size_t)v["byteOffset"].i64(0), vl = (size_t)v["byteLength"].i64(0), vs = (size_t)v["byteStride"].i64(0);
+            size_t buf = 0, vo = 0, vl = 0, vs = 0;
+            if (!field(v, "buffer", ~(size_t)0 >> 24, buf) || !field(v, "byteOffset", 0, vo) || !field(v, "byteLength", 0, vl) || !field(v, "byteStride", 0, vs))
+                return fail("bufferView " + std::to_string(acc.bufferView) + ": buffer / byteOffset / byteLength / byteStride must be non-negative integers");
             if (buf >= buffers.size() || vo + vl > buffers[buf].size()) return fail("bufferView " + std::to_string(acc.bufferView) + " overruns its buffer");
             size_t elem = (size_t)cs * acc.components;
             acc.stride = vs ? vs : elem;
@@ -368,6 +384,7 @@ bool process_primitive(const Document& doc, const json::Value& prim, hobbyrt::Sc
     const json::Value* matRef = prim.find("material");
     const int matIdx = matRef ? (int)matRef->i64(-1) + offsets.materialOffset : -1;
     res.minimalPrim.m_MaterialIndex = matIdx;
+    if (matRef && (matIdx < offsets.materialOffset || (size_t)matIdx >= scene.m_Materials.size())) return fail("primitive references material " + std::to_string(matRef->i64(-1)) + ", which does not exist");
     if (!posAcc || mode != 4) { if (posAcc) t_warnings.push_back("primitive skipped: only TRIANGLES (mode 4) is handled"); return true; }
     if (!tangAcc && (!normAcc || !uvAcc) && matIdx >= 0 && (size_t)matIdx < scene.m_Materials.size()) scene.m_Materials[(size_t)matIdx].m_NormalTexture = -1;   // :1815-1822
 
@@ -508,6 +525,8 @@ bool ProcessNodesAndHierarchy(const Document& doc, hobbyrt::Scene& scene, const 
         hobbyrt::Scene::Node& node = scene.m_Nodes[ni + (size_t)offsets.nodeOffset];
         node.m_Name = cn["name"].str("");
         node.m_MeshIndex = cn.find("mesh") ? (int)cn["mesh"].i64(-1) + offsets.meshOffset : -1;
+        if (cn.find("mesh") && (node.m_MeshIndex < offsets.meshOffset || (size_t)node.m_MeshIndex >= offsets.meshOffset + doc.root["meshes"].size()))
+            return fail("node " + std::to_string(ni) + " references mesh " + std::to_string(cn["mesh"].i64(-1)) + ", which does not exist");
         node.m_CameraIndex = cn.find("camera") ? (int)cn["camera"].i64(-1) + offsets.cameraOffset : -1;
         const json::Value* lightRef = cn["extensions"]["KHR_lights_punctual"].find("light");
         node.m_LightIndex = lightRef ? (int)lightRef->i64(-1) + offsets.lightOffset : -1;
@@ -546,6 +565,15 @@ bool ProcessNodesAndHierarchy(const Document& doc, hobbyrt::Scene& scene, const 
     for (size_t i = 0; i < nodes.size(); ++i)
         if (scene.m_Nodes[i + (size_t)offsets.nodeOffset].m_Parent == -1) ComputeWorldTransforms(scene, (int)i + offsets.nodeOffset, Matrix::Identity());
     for (size_t ni = 0; ni < nodes.size(); ++ni) scene.UpdateNodeBoundingSphere((int)ni + offsets.nodeOffset);
+    // The reference requires every light to sit on a node (Scene::Light::m_NodeIndex "must be valid", src/Scene.h:247) and asserts
+    // otherwise; a punctual light no node instantiates gets an identity node here so that the light buffer stays well defined.
+    for (size_t li = (size_t)offsets.lightOffset; li < scene.m_Lights.size(); ++li)
+        if (scene.m_Lights[li].m_NodeIndex < 0 || (size_t)scene.m_Lights[li].m_NodeIndex >= scene.m_Nodes.size()) {
+            t_warnings.push_back("light " + std::to_string(li) + " is not instantiated by any node: placed at the origin");
+            hobbyrt::Scene::Node n; n.m_LightIndex = (int)li;
+            scene.m_Lights[li].m_NodeIndex = (int)scene.m_Nodes.size();
+            scene.m_Nodes.push_back(n);
+        }
     return true;
 }
 
@@ -698,6 +726,18 @@ bool LoadSceneFile(Scene& scene, const std::string& scenePath, bool useMeshCache
     scene.FinalizeLoadedScene();
     LoadTexturesFromImages(scene, sceneDir);
     scene.UpdateMaterialsAndCreateConstants();
+    // A primitive without a material carries index -1 into PerInstanceData (src/Scene.cpp:292); the reference's shader then reads
+    // past the material buffer, which D3D12 defines as zeros. The same result without the out-of-range read: one all-zero
+    // MaterialConstants appended, and those instances point at it.
+    bool needZero = false;
+    for (const srrhi::PerInstanceData& inst : scene.m_InstanceData) if (inst.m_MaterialIndex >= scene.m_MaterialConstants.size()) needZero = true;
+    if (needZero) {
+        t_warnings.push_back("primitives without a material use an all-zero material (the reference reads out of range there)");
+        const uint32_t zeroIndex = (uint32_t)scene.m_MaterialConstants.size();
+        scene.m_MaterialConstants.push_back(srrhi::MaterialConstants{});
+        scene.m_MaterialConstantsBuffer = { scene.m_MaterialConstants.data(), scene.m_MaterialConstants.size() * sizeof(srrhi::MaterialConstants) };
+        for (srrhi::PerInstanceData& inst : scene.m_InstanceData) if (inst.m_MaterialIndex >= zeroIndex) inst.m_MaterialIndex = zeroIndex;
+    }
     scene.CreateAndUploadLightBuffer();
     if (!scene.m_Cameras.empty()) { scene.SetCameraFromSceneCamera(scene.m_Cameras[0]); scene.m_SelectedCameraIndex = 0; }
     return true;

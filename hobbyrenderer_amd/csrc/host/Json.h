@@ -32,7 +32,7 @@ struct Value {
     float f32(float dflt) const { return type == Number ? (float)number : dflt; }
     int64_t i64(int64_t dflt) const { return type == Number ? (isInteger ? integer : (int64_t)number) : dflt; }
     bool flag(bool dflt) const { return type == Bool ? boolean : dflt; }
-    const std::string& str(const std::string& dflt) const { return type == String ? string : dflt; }
+    std::string str(const std::string& dflt) const { return type == String ? string : dflt; }   // by value: callers bind it to references
 };
 
 // Parses `n` bytes; on failure returns false and sets err to "offset N: reason".

@@ -168,12 +168,5 @@ void BuildCornellScene(Scene& s)
     Finish(s);
 }
 
-int GenerateAtmosphereLuts(Scene& s, int nthreads)
-{
-    s.m_BrunetonTransmittance.assign(256u * 64u * 4u, 0.0f);
-    s.m_BrunetonScattering.assign(256u * 128u * 32u * 4u, 0.0f);
-    s.m_BrunetonIrradiance.assign(64u * 16u * 4u, 0.0f);
-    return hrpt_precompute_atmosphere(s.m_BrunetonTransmittance.data(), s.m_BrunetonScattering.data(), s.m_BrunetonIrradiance.data(), nthreads);
-}
 
 } // namespace hobbyrt

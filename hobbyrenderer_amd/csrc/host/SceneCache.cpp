@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <system_error>
 
@@ -163,7 +164,10 @@ int hrsc_cooked_mesh_load(const char* path, HrscCookedMesh** out)
     if (!std::filesystem::exists(path, ec)) { t_error = std::string("hrsc_cooked_mesh_load: no such file: ") + path; return HRSC_ERR_IO; }
     auto box = new CookedMeshBox();
     std::vector<hobbyrt::Scene::Mesh> meshes;
-    if (!SceneCache::LoadCookedMesh(path, meshes, box->meshData, box->meshlets, box->mv, box->mt, box->vertices, box->indices)) {
+    bool loaded = false;
+    try { loaded = SceneCache::LoadCookedMesh(path, meshes, box->meshData, box->meshlets, box->mv, box->mt, box->vertices, box->indices); }
+    catch (const std::exception& e) { t_error = std::string("cache file rejected: ") + e.what(); }
+    if (!loaded) {
         const bool io = t_error.rfind("cannot read", 0) == 0;
         delete box;
         return io ? HRSC_ERR_IO : HRSC_ERR_FORMAT;

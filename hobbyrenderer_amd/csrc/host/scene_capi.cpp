@@ -1,5 +1,6 @@
 // scene_capi.cpp -- C ABI of the glTF ingestion (include/hobbyrt_scene.h) over hobbyrt::Scene / SceneLoader.
 #include <cstdlib>
+#include <exception>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,7 +31,9 @@ int hrsc_scene_load(const char* path, uint32_t flags, HrscScene** out)
     *out = nullptr;
     std::error_code ec;
     if (!std::filesystem::exists(path, ec)) { SceneCache::SetLastError(std::string("hrsc_scene_load: no such file: ") + path); return HRSC_ERR_IO; }
-    HrscScene* s = new HrscScene();
+    HrscScene* s = nullptr;
+    try {
+    s = new HrscScene();
     const bool useCache = (flags & HRSC_LOAD_USE_MESH_CACHE) != 0;
     const std::filesystem::path p(path), cache = p.parent_path() / (p.stem().string() + "_mesh.bin");
     s->fromCache = useCache && SceneCache::IsCacheValid(cache, p);
@@ -50,6 +53,11 @@ int hrsc_scene_load(const char* path, uint32_t flags, HrscScene** out)
     }
     *out = s;
     return HRSC_OK;
+    } catch (const std::exception& e) {       // no exception crosses the C boundary (allocation failure on absurd counts, ...)
+        delete s;
+        SceneCache::SetLastError(std::string("hrsc_scene_load: ") + e.what());
+        return HRSC_ERR_FORMAT;
+    }
 }
 
 void hrsc_scene_free(HrscScene* scene) { delete scene; }
@@ -85,7 +93,9 @@ int hrsc_decode_image(const uint8_t* bytes, size_t n, uint32_t* width, uint32_t*
 {
     if (!bytes || !width || !height || !rgba) { SceneCache::SetLastError("hrsc_decode_image: null argument"); return HRSC_ERR_INVALID_ARG; }
     hobbyrt::Image img; std::string err;
-    if (!hobbyrt::DecodeImage(bytes, n, img, err)) { SceneCache::SetLastError("hrsc_decode_image: " + err); return HRSC_ERR_FORMAT; }
+    bool decoded = false;
+    try { decoded = hobbyrt::DecodeImage(bytes, n, img, err); } catch (const std::exception& e) { err = e.what(); }
+    if (!decoded) { SceneCache::SetLastError("hrsc_decode_image: " + err); return HRSC_ERR_FORMAT; }
     *rgba = static_cast<uint8_t*>(std::malloc(img.rgba.size() ? img.rgba.size() : 1));
     if (!*rgba) { SceneCache::SetLastError("hrsc_decode_image: out of memory"); return HRSC_ERR_IO; }
     std::memcpy(*rgba, img.rgba.data(), img.rgba.size());

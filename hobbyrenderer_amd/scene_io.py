@@ -6,7 +6,6 @@ import os
 
 import numpy as np
 
-from . import native  # noqa: F401  (loads torch's HIP runtime and libhobbyrt_pt.so, which libhobbyrt_scene.so links)
 from . import structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

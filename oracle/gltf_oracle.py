@@ -585,6 +585,11 @@ def load(path):
     for ni in range(len(nodes_json)):
         if nodes[ni]["parent"] == -1:
             walk(ni, np.identity(4, dtype=np.float32))
+    for li, l in enumerate(lights):        # a light no node instantiates sits on an identity node (the reference asserts instead)
+        if l["node"] < 0:
+            l["node"] = len(nodes)
+            ident = np.identity(4, dtype=np.float32)
+            nodes.append({"mesh": -1, "camera": -1, "light": li, "children": [], "parent": -1, "local": ident, "world": ident})
     # FinalizeLoadedScene: one instance per (node, primitive); buckets opaque / masked / transparent, static before dynamic
     buckets = [[] for _ in range(6)]
     for ni, node in enumerate(nodes):
@@ -617,6 +622,10 @@ def load(path):
             if refs[key] != -1:
                 g[field] = textures[refs[key]]["bindless"]
         out_mats[i] = g
+    if len(instances) and (instances["m_MaterialIndex"] >= len(out_mats)).any():     # material-less primitives -> one all-zero material
+        zero = len(out_mats)
+        out_mats = np.concatenate([out_mats, np.zeros(1, MaterialConstants)])
+        instances["m_MaterialIndex"] = np.where(instances["m_MaterialIndex"] >= zero, zero, instances["m_MaterialIndex"])
     # light buffer
     gpu_lights = np.zeros(len(lights), GPULight)
     for i, l in enumerate(lights):

@@ -235,3 +235,25 @@ def test_loaded_scene_renders_like_the_oracle(tmp_path, luts):
     assert st.bvhTriangleCount == len(sc.indices) // 3 * 0 + sum(int(sc.mesh_data["m_IndexCounts"][i][0]) // 3 for i in sc.instances["m_MeshDataIndex"])
     assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
     assert (acc[..., :3] > 0).any() and cam["fov_y"] > 0
+
+
+def test_unreferenced_light_and_material_less_primitive(tmp_path, luts):
+    """A punctual light no node instantiates gets an identity node; a primitive without a material points at one all-zero
+    MaterialConstants (what the reference's out-of-range read yields on D3D12). Both sides of the comparison do the same."""
+    a = Asset()
+    p, n, uv, i = grid(2, 2, 1.0)
+    a.add_primitive(0, p, i, n, uv)                       # no material
+    a.add_primitive(0, p + np.float32(0.5), i, n, uv, material=0)
+    a.j["materials"] = [{"pbrMetallicRoughness": {"baseColorFactor": [0.5, 0.5, 0.5, 1.0]}}]
+    a.j["extensions"] = {"KHR_lights_punctual": {"lights": [{"type": "point", "intensity": 5.0}, {"type": "spot", "intensity": 2.0}]}}
+    a.j["nodes"] = [{"mesh": 0}, {"extensions": {"KHR_lights_punctual": {"light": 1}}, "translation": [0, 2, 0]}]
+    path = str(tmp_path / "loose.gltf")
+    a.write(path)
+    loaded = scene_io.load_gltf(path, luts)
+    _assert_same_scene(loaded, G.load(path))
+    m = loaded.arrays.materials
+    assert len(m) == 2 and not m[1].tobytes().strip(b"\0") and set(loaded.arrays.instances["m_MaterialIndex"]) == {0, 1}
+    assert len(loaded.arrays.lights) == 3 and any("not instantiated" in w for w in loaded.warnings) and any("all-zero material" in w for w in loaded.warnings)
+    # and such a scene uploads: every index the loader hands out is in range
+    sc = loaded.arrays
+    assert sc.instances["m_MaterialIndex"].max() < len(sc.materials)

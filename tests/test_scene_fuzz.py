@@ -1,0 +1,29 @@
+"""Robustness of the scene-format readers (JSON, PNG/DDS, RLFY, glTF/GLB): a mutation driver built with AddressSanitizer + UBSan
+(`make -C hobbyrenderer_amd/csrc fuzz`, CPU only) must survive a few thousand corrupted inputs per format without a sanitizer report,
+an uncaught exception or a crash, and whatever it accepts must be internally consistent (indices inside their arrays)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from gltf_helpers import build_showcase
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hobbyrenderer_amd", "csrc")
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_mutated_inputs_do_not_crash_the_readers(tmp_path, seed):
+    subprocess.check_call(["make", "-C", CSRC, "fuzz"], stdout=subprocess.DEVNULL)
+    d = str(tmp_path)
+    gltf = build_showcase(d)
+    glb = build_showcase(d, "glb", "glbcase")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "cornell_mesh.bin"), os.path.join(d, "seed.bin"))
+    shutil.copy(gltf, os.path.join(d, "doc.json"))
+    files = [gltf, glb, os.path.join(d, "seed.bin"), os.path.join(d, "doc.json"), os.path.join(d, "albedo rgba.png"), os.path.join(d, "orm16.png"),
+             os.path.join(d, "emissive_pal.png")]
+    env = dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
+    r = subprocess.run([os.path.join(CSRC, "build", "scene_fuzz"), "1500", str(seed), *files], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "no crash" in r.stdout
