@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -160,7 +162,7 @@ const char* hrpt_last_error(const HrptContext* c)
     return copy.c_str();
 }
 
-int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
+static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     if (!s) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: null scene");
@@ -310,7 +312,7 @@ float hrpt_halton(uint32_t index, uint32_t base)   // src/Utilities.cpp:67-79
     return result;
 }
 
-int hrpt_render(HrptContext* c, const HrptFrameParams* p)
+static int render_impl(HrptContext* c, const HrptFrameParams* p)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     if (!p) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: null params");
@@ -345,6 +347,20 @@ int hrpt_render(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
     c->timed = true;
     return HRPT_OK;
+}
+
+// No C++ exception crosses the C boundary: host-side allocation failures (std::bad_alloc on very large scenes) become status codes.
+int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
+{
+    try { return upload_scene_impl(c, s); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_upload_scene: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_upload_scene: ") + e.what()); }
+}
+int hrpt_render(HrptContext* c, const HrptFrameParams* p)
+{
+    try { return render_impl(c, p); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_render: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_render: ") + e.what()); }
 }
 
 int hrpt_set_stream(HrptContext* c, void* hipStream, int useCallerStream)
@@ -413,6 +429,33 @@ int hrpt_resolve_device(HrptContext* c, const float* accumulationDevice, float* 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_resolve(reinterpret_cast<const float4*>(accumulationDevice), reinterpret_cast<float4*>(outputDevice), (uint32_t)pixelCount,
                               static_cast<hipStream_t>(stream)));
+    return HRPT_OK;
+}
+
+int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint64_t count, uint32_t flags)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: no scene uploaded");
+    if (count == 0) return HRPT_OK;
+    if (!rays || !hits) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: null array");
+    if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
+    if (count > (1ull << 31)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: too many rays in one call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool shadow = (flags & 0xFFu) == HRPT_RAYS_SHADOW;
+    if (flags & HRPT_RAYS_DEVICE_POINTERS) {
+        HIP_TRY(c, launch_trace_rays(c->view, rays, hits, count, shadow, c->stream));
+        return HRPT_OK;
+    }
+    HrptRay* dRays = nullptr; HrptRayHit* dHits = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dRays), count * sizeof(HrptRay));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dHits), count * sizeof(HrptRayHit));
+    if (e == hipSuccess) e = hipMemcpyAsync(dRays, rays, count * sizeof(HrptRay), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_trace_rays(c->view, dRays, dHits, count, shadow, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits, dHits, count * sizeof(HrptRayHit), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dRays) (void)hipFree(dRays);
+    if (dHits) (void)hipFree(dHits);
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? HRPT_ERR_OUT_OF_MEMORY : HRPT_ERR_HIP, std::string("hrpt_trace_rays: ") + hipGetErrorString(e));
     return HRPT_OK;
 }
 

@@ -29,6 +29,9 @@ hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstan
 hipError_t launch_post_chain(const float4* hdr, float4* display, uint32_t pixelCount, const HrptPostParams& params, uint32_t* histogram,
                              float* exposure, hipStream_t stream);
 
+// Batch ray queries (hrpt_trace_rays): closest hit with the candidate rules of TraceRayStandard, or NEE-style visibility.
+hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRayHit* hits, uint64_t count, bool shadow, hipStream_t stream);
+
 // Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).
 hipError_t launch_f16_table(float* out, hipStream_t stream);
 

@@ -119,6 +119,40 @@ hipError_t launch_f16_table(float* out, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Stand-alone ray queries over the scene's acceleration structure: TraceRayStandard (RaytracingCommon.hlsli:138-198) and
+// CalculateRTShadow<true> (CommonLighting.hlsli:380-496) for callers other than the path tracer (the reference's DDGI probe trace,
+// ray-traced shadows and BRDF ray tracing share exactly these two includes). One thread per ray, 2-wide tree, private stack.
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void pt_trace_rays_kernel(SceneView s, const HrptRay* __restrict__ rays, HrptRayHit* __restrict__ hits, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    HrptRay r = rays[i];
+    HrptRayHit out; out.t = 0.0f; out.u = 0.0f; out.v = 0.0f; out.instance = 0; out.primitive = 0; out.hit = 0; out.rng = r.rng; out.pad = 0;
+    GlobalBvh bvh; bvh.nodes = s.nodes; bvh.tris = s.tris;
+    PrivateStack stack;
+    f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    const bool finite = d.x == d.x && d.y == d.y && d.z == d.z && o.x == o.x && o.y == o.y && o.z == o.z;
+    if (SHADOW) {
+        out.t = finite ? shadow_query(s, bvh, o, d, r.tmax, stack) : 1.0f;     // visibility in [0, 1]
+        out.hit = out.t < 1.0f ? 1u : 0u;
+    } else if (finite) {
+        Ray ray; ray.o = o; ray.d = d; ray.tmin = r.tmin; ray.tmax = r.tmax;
+        uint32_t rng = r.rng; Hit h;
+        if (trace_standard(s, bvh, ray, rng, stack, h)) { out.t = h.t; out.u = h.u; out.v = h.v; out.instance = h.inst; out.primitive = h.prim; out.hit = 1; }
+        out.rng = rng;
+    }
+    hits[i] = out;
+}
+hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRayHit* hits, uint64_t count, bool shadow, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    dim3 grid((unsigned)((count + 255) / 256));
+    if (shadow) hipLaunchKernelGGL((pt_trace_rays_kernel<true>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+    else hipLaunchKernelGGL((pt_trace_rays_kernel<false>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream)
 {
     if (pixelCount == 0) return hipSuccess;

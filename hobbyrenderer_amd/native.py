@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_trace_rays", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -51,6 +51,7 @@ lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
+lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
@@ -160,6 +161,13 @@ class PathTracerContext:
         """Output = accum.rgb / accum.a over caller-owned device images, asynchronously on `hip_stream` (integer handle)."""
         self._check(lib.hrpt_resolve_device(self._h, C.c_void_p(int(accumulation_ptr)), C.c_void_p(int(output_ptr)), int(pixel_count),
                                             C.c_void_p(int(hip_stream))))
+
+    def trace_rays(self, rays, shadow=False):
+        """rays: structured array of S.Ray; returns a structured array of S.RayHit (see hrpt_trace_rays)."""
+        rays = np.ascontiguousarray(rays, S.Ray)
+        hits = np.zeros(len(rays), S.RayHit)
+        self._check(lib.hrpt_trace_rays(self._h, rays.ctypes.data, hits.ctypes.data, len(rays), S.RAYS_SHADOW if shadow else S.RAYS_CLOSEST))
+        return hits
 
     def set_bvh_builder(self, builder):
         """S.BVH_BUILDER_HOST_SAH (default) or S.BVH_BUILDER_GPU_LBVH; used by the next upload_scene."""

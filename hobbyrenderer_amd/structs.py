@@ -94,6 +94,11 @@ class Stats(C.Structure):
                 ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("bvhMaxDepth", C.c_uint32)]
 
 
+Ray = np.dtype([("origin", f32, 3), ("tmin", f32), ("direction", f32, 3), ("tmax", f32), ("rng", u32), ("pad", u32, 3)])       # HrptRay, 48 B
+RayHit = np.dtype([("t", f32), ("u", f32), ("v", f32), ("instance", u32), ("primitive", u32), ("hit", u32), ("rng", u32), ("pad", u32)])   # HrptRayHit, 32 B
+RAYS_CLOSEST, RAYS_SHADOW, RAYS_DEVICE_POINTERS = 0, 1, 0x100
+
+
 class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
     _fields_ = [("requestedBuilder", C.c_uint32), ("usedBuilder", C.c_uint32), ("buildMs", C.c_float), ("deviceBuildMs", C.c_float),
                 ("triangleCount", C.c_uint32), ("nodeCount", C.c_uint32), ("node4Count", C.c_uint32), ("maxDepth", C.c_uint32),

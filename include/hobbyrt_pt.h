@@ -280,6 +280,22 @@ typedef struct HrptBuildInfo {
 } HrptBuildInfo;                                /* 48 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
 
+/* ---- stand-alone ray queries ("other inline-RT consumers") ------------------------------------------
+ * The two queries every inline-ray-tracing pass of the reference is built from, over the uploaded scene:
+ *   HRPT_RAYS_CLOSEST  TraceRayStandard (src/shaders/RaytracingCommon.hlsli:138-198): closest hit, MASK candidates alpha-tested,
+ *                      BLEND candidates committed stochastically from the ray's own RNG state (returned advanced in HrptRayHit::rng)
+ *   HRPT_RAYS_SHADOW   CalculateRTShadow<true> (src/shaders/CommonLighting.hlsli:380-496): origin = shaded point, direction = L,
+ *                      tmax = distance to the light; the visibility in [0, 1] comes back in HrptRayHit::t (tmin is ignored:
+ *                      the query applies its own 0.01 bias)
+ * rays / hits are host arrays unless HRPT_RAYS_DEVICE_POINTERS is set (then both are device pointers and the call is asynchronous
+ * on the context stream). */
+typedef struct HrptRay    { float origin[3]; float tmin; float direction[3]; float tmax; uint32_t rng; uint32_t pad[3]; } HrptRay;       /* 48 B */
+typedef struct HrptRayHit { float t, u, v; uint32_t instance, primitive, hit, rng, pad; } HrptRayHit;                                  /* 32 B */
+#define HRPT_RAYS_CLOSEST 0u
+#define HRPT_RAYS_SHADOW  1u
+#define HRPT_RAYS_DEVICE_POINTERS 0x100u
+int  hrpt_trace_rays(HrptContext* ctx, const HrptRay* rays, HrptRayHit* hits, uint64_t count, uint32_t flags);
+
 /* Host read-back (synchronises). bytes must be width*height*16. */
 int  hrpt_read_accumulation(HrptContext* ctx, float* rgba, size_t bytes);
 int  hrpt_read_output(HrptContext* ctx, float* rgba, size_t bytes);

@@ -66,6 +66,10 @@ def lib():
             getattr(L, n).argtypes = [C.c_float]
         L.or_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_float)]
+        L.or_trace_standard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_float)]
+        L.or_shadow_query.restype = C.c_float
+        L.or_shadow_query.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
         L.or_sky_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         L.or_sky_radiance.restype = None
         L.or_sun_radiance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
@@ -131,6 +135,18 @@ class Oracle:
         if not hit:
             return None
         return inst.value, prim.value, float(bary[0]), float(bary[1]), float(t.value)
+
+    def trace_standard(self, origin, direction, tmin, tmax, rng):
+        """TraceRayStandard: returns (hit, inst, prim, u, v, t, rng_after)."""
+        o = np.ascontiguousarray(origin, np.float32); d = np.ascontiguousarray(direction, np.float32)
+        inst, prim, t, r = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_uint32(int(rng))
+        bary = np.zeros(2, np.float32)
+        hit = lib().or_trace_standard(self._h, o.ctypes.data, d.ctypes.data, tmin, tmax, C.byref(r), C.byref(inst), C.byref(prim), bary.ctypes.data, C.byref(t))
+        return bool(hit), inst.value, prim.value, float(bary[0]), float(bary[1]), float(t.value), r.value
+
+    def shadow_query(self, world_pos, direction, max_dist):
+        p = np.ascontiguousarray(world_pos, np.float32); d = np.ascontiguousarray(direction, np.float32)
+        return float(lib().or_shadow_query(self._h, p.ctypes.data, d.ctypes.data, max_dist))
 
     def sky_radiance(self, camera_pos, view_ray, sun_dir, sun_intensity=1.0, add_sun_disk=True):
         out = np.zeros(3, np.float32)

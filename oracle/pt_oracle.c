@@ -1345,6 +1345,25 @@ int or_trace_closest(OrContext* c, const float o[3], const float d[3], float tmi
     return 1;
 }
 
+/* TraceRayStandard (RaytracingCommon.hlsli:138-198) and CalculateRTShadow<true> (CommonLighting.hlsli:380-496) as stand-alone ray
+ * queries: what the other inline-ray-tracing passes of the reference call. rng is the caller's RNG state (BLEND
+ * candidates draw from it). Checkers for hrpt_trace_rays. */
+int or_trace_standard(OrContext* c, const float o[3], const float d[3], float tmin, float tmax, uint32_t* rng,
+                      uint32_t* inst, uint32_t* prim, float bary[2], float* t)
+{
+    Tls tl; memset(&tl, 0, sizeof tl); tl.c = c; tl.brute = 0;
+    Ray r; r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]); r.tmin = tmin; r.tmax = tmax;
+    Hit h;
+    if (!trace_ray_standard(&tl, &r, rng, &h)) return 0;
+    *inst = h.inst; *prim = h.prim; bary[0] = h.u; bary[1] = h.v; *t = h.t;
+    return 1;
+}
+float or_shadow_query(OrContext* c, const float worldPos[3], const float L[3], float maxDist)
+{
+    Tls tl; memset(&tl, 0, sizeof tl); tl.c = c; tl.brute = 0;
+    return calculate_rt_shadow(&tl, V3(worldPos[0], worldPos[1], worldPos[2]), V3(L[0], L[1], L[2]), maxDist);
+}
+
 /* ------------------------------------------------------------------ HDR post chain */
 float or_log2(float x) { return hrt_log2(x); }
 float or_exp2(float x) { return hrt_exp2(x); }

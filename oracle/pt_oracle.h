@@ -77,6 +77,10 @@ float    or_sin(float x); float or_cos(float x); float or_exp(float x);
 /* one closest-hit query against the context BVH (or brute force); returns 1 on hit */
 int      or_trace_closest(OrContext* ctx, const float origin[3], const float dir[3], float tmin, float tmax,
                           int bruteForce, uint32_t* inst, uint32_t* prim, float bary[2], float* t);
+/* TraceRayStandard / CalculateRTShadow<true> as stand-alone queries (checkers for hrpt_trace_rays); 1 on hit */
+int      or_trace_standard(OrContext* ctx, const float origin[3], const float dir[3], float tmin, float tmax, uint32_t* rng,
+                           uint32_t* inst, uint32_t* prim, float bary[2], float* t);
+float    or_shadow_query(OrContext* ctx, const float worldPos[3], const float L[3], float maxDist);
 /* GetAtmosphereSkyRadiance / GetAtmosphereSunRadiance (Atmosphere.hlsli:569-601) */
 void     or_sky_radiance(OrContext* ctx, const float cameraPos[3], const float viewRay[3], const float sunDir[3],
                          float sunIntensity, int addSunDisk, float out[3]);
