@@ -432,6 +432,55 @@ int hrpt_resolve_device(HrptContext* c, const float* accumulationDevice, float* 
     return HRPT_OK;
 }
 
+int hrpt_allgather(HrptContext* const* ranks, int n)
+{
+    if (!ranks || n <= 0) return HRPT_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; ++i) if (!ranks[i]) return HRPT_ERR_INVALID_ARGUMENT;
+    HrptContext* c0 = ranks[0];
+    const uint32_t W = c0->width, H = c0->height;
+    if (!c0->dAccum || W == 0 || H == 0) return fail(c0, HRPT_ERR_INVALID_ARGUMENT, "hrpt_allgather: hrpt_resize not called");
+    if (H % (uint32_t)n != 0) return fail(c0, HRPT_ERR_INVALID_ARGUMENT, "hrpt_allgather: image height must be a multiple of the number of ranks");
+    for (int i = 0; i < n; ++i) {
+        if (ranks[i]->width != W || ranks[i]->height != H || !ranks[i]->dAccum) return fail(c0, HRPT_ERR_INVALID_ARGUMENT, "hrpt_allgather: contexts differ in image size");
+        for (int j = 0; j < i; ++j) if (ranks[j] == ranks[i]) return fail(c0, HRPT_ERR_INVALID_ARGUMENT, "hrpt_allgather: the same context appears twice");
+    }
+    const size_t rows = H / (uint32_t)n, bandBytes = rows * (size_t)W * sizeof(float4);
+    std::vector<hipEvent_t> sent((size_t)n, nullptr);
+    auto cleanup = [&]() { for (hipEvent_t e : sent) if (e) (void)hipEventDestroy(e); };
+    // every rank pushes its band to all the others on its own stream, then marks the point where its sends are enqueued
+    for (int i = 0; i < n; ++i) {
+        HrptContext* src = ranks[i];
+        hipError_t e = hipSetDevice(src->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sent[(size_t)i], hipEventDisableTiming);
+        const size_t off = (size_t)i * rows * W;
+        for (int j = 0; j < n && e == hipSuccess; ++j) {
+            if (j == i) continue;
+            HrptContext* dst = ranks[j];
+            // the destination band must not be in use by the destination's earlier work (e.g. its previous resolve): order behind it
+            hipEvent_t ready = nullptr;
+            e = hipSetDevice(dst->device);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ready, dst->stream);
+            if (e == hipSuccess) e = hipSetDevice(src->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(src->stream, ready, 0);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->dAccum + off, dst->device, src->dAccum + off, src->device, bandBytes, src->stream);
+            if (ready) (void)hipEventDestroy(ready);
+        }
+        if (e == hipSuccess) e = hipEventRecord(sent[(size_t)i], src->stream);
+        if (e != hipSuccess) { cleanup(); return fail(c0, HRPT_ERR_HIP, std::string("hrpt_allgather (send): ") + hipGetErrorString(e)); }
+    }
+    // every rank waits for all senders, then resolves its now complete image
+    for (int j = 0; j < n; ++j) {
+        HrptContext* dst = ranks[j];
+        hipError_t e = hipSetDevice(dst->device);
+        for (int i = 0; i < n && e == hipSuccess; ++i) if (i != j) e = hipStreamWaitEvent(dst->stream, sent[(size_t)i], 0);
+        if (e == hipSuccess) e = launch_resolve(dst->dAccum, dst->dOutput, W * H, dst->stream);
+        if (e != hipSuccess) { cleanup(); return fail(c0, HRPT_ERR_HIP, std::string("hrpt_allgather (receive): ") + hipGetErrorString(e)); }
+    }
+    cleanup();      // destroying a recorded event is deferred by the runtime until the waits that reference it have run
+    return HRPT_OK;
+}
+
 int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint64_t count, uint32_t flags)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_trace_rays", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -51,6 +51,7 @@ lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
+lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
 lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
@@ -79,6 +80,14 @@ def precompute_atmosphere(nthreads=0):
     if rc != 0:
         raise HrptError(rc, "hrpt_precompute_atmosphere")
     return t, s, i
+
+
+def allgather(contexts):
+    """hrpt_allgather over PathTracerContext objects living in this process (one per GPU, or several on one GPU)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib.hrpt_allgather(arr, len(contexts))
+    if rc != 0:
+        raise HrptError(rc, lib.hrpt_last_error(contexts[0]._h).decode() if contexts else "hrpt_allgather")
 
 
 class PathTracerContext:

@@ -280,6 +280,15 @@ typedef struct HrptBuildInfo {
 } HrptBuildInfo;                                /* 48 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
 
+/* ---- in-process multi-GPU: one context per GPU inside ONE process ------------------------------------
+ * Rank i of n has rendered the row band [i*H/n, (i+1)*H/n) of its accumulation image (HrptFrameParams::tile*; H must be a
+ * multiple of n, every context the same size). hrpt_allgather sends every band to every other context with
+ * hipMemcpyPeerAsync (xGMI between GPUs, a plain device copy when two contexts share a GPU), orders the copies against each
+ * context's stream with events, and resolves Output = rgb / a on every context. Asynchronous: follow with hrpt_synchronize on
+ * the contexts that are read. The one-process-per-GPU form of the same exchange (torch.distributed / RCCL) is
+ * hobbyrenderer_amd/distributed.py. */
+int  hrpt_allgather(HrptContext* const* ranks, int n);
+
 /* ---- stand-alone ray queries ("other inline-RT consumers") ------------------------------------------
  * The two queries every inline-ray-tracing pass of the reference is built from, over the uploaded scene:
  *   HRPT_RAYS_CLOSEST  TraceRayStandard (src/shaders/RaytracingCommon.hlsli:138-198): closest hit, MASK candidates alpha-tested,

@@ -76,3 +76,37 @@ def test_device_tensor_view_and_rccl_allgather(luts):
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_in_process_allgather_of_bands(luts):
+    """hrpt_allgather: n contexts inside one process (here all on GPU 0, so the peer copies are plain device copies), each renders
+    its row band, the bands are exchanged context-to-context and every context ends with the full image == a single-context render."""
+    from hobbyrenderer_amd import native
+    from hobbyrenderer_amd.native import PathTracerContext
+    w, h, n, spp = 96, 54, 3, 2
+    sc, view, pos, cfg = scenes.config_cornell(luts, w, h)
+    cb = scenes.fill_constants(view, pos, sc, 0, 4)
+    ref = PathTracerContext(0); ref.upload_scene(sc); ref.resize(w, h)
+    ref.render(cb, accum_count=spp)
+    want_acc, want_out = ref.read_accumulation(), ref.read_output(); ref.close()
+    ctxs = []
+    try:
+        for r in range(n):
+            c = PathTracerContext(0); c.upload_scene(sc); c.resize(w, h); ctxs.append(c)
+        rows = h // n
+        for frame in range(2):                      # twice: the second exchange has to order itself behind the first resolve
+            for r, c in enumerate(ctxs):
+                c.render(cb, accum_count=spp, tile=(0, r * rows, w, (r + 1) * rows))
+            native.allgather(ctxs)
+            for c in ctxs:
+                c.synchronize()
+                assert np.array_equal(c.read_accumulation().view(np.uint32), want_acc.view(np.uint32))
+                assert np.array_equal(c.read_output().view(np.uint32), want_out.view(np.uint32))
+        with pytest.raises(native.HrptError):
+            native.allgather([ctxs[0], ctxs[0]])
+        ctxs[1].resize(w, h + 3)
+        with pytest.raises(native.HrptError):
+            native.allgather(ctxs)
+    finally:
+        for c in ctxs:
+            c.close()
