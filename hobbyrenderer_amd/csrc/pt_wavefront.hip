@@ -657,10 +657,13 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     for (uint32_t first = 0; first < accumCount; first += sppPerBatch) {
         const uint32_t spp = (accumCount - first) < sppPerBatch ? (accumCount - first) : sppPerBatch;
         a.spp = spp; a.numSamples = (uint32_t)(pixelsPadded * spp);
-        // segment size: large segments amortise the partially filled last iteration, small ones give every SIMD several
-        // waves when the batch is small (tile-sharded multi-GPU runs): aim for >= 4 waves per SIMD slot
-        // 256 measured best on MI355X for both the full 1080p x 8 spp batch and a 135-row band (scripts/seg_sweep.py)
-        uint32_t shift = st.segmentShift ? st.segmentShift : 8;
+        // segment size: large segments amortise the partially filled last 64-lane iteration of every segment (after compaction a
+        // segment holds ~80 % / 65 % / 53 % of its slots at bounces 1 / 2 / 3), small ones give every SIMD several waves when the batch is
+        // small (tile-sharded multi-GPU runs) and balance uneven per-entry work (several lights per shadow entry). Measured on MI355X
+        // (scripts/sweep_env.sh, scripts/seg_sweep.py): 512 wins for full-frame single-light batches (-3 % config 2, -4 % config 4),
+        // 256 for a 135-row band (0.76 vs 0.89 ms) and for the three-light glass scene.
+        const bool largeBatch = a.numSamples >= (8u << 20) && maxLights == 1;
+        uint32_t shift = st.segmentShift ? st.segmentShift : (largeBatch ? 9u : 8u);
         if (shift < 6) shift = 6;
         if (shift > 10) shift = 10;
         a.segShift = shift;
