@@ -41,6 +41,7 @@ struct WavefrontState {
     uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
     bool forceGlobalBvh = false;
+    bool drainSegments = false;        // wf_extend finishes every ray of a segment before it opens the next one (A/B knob)
     bool serialShadow = false;         // true: wf_shadow runs in stream order instead of concurrently with the next wf_extend
     // second stream + fork/join events: wf_shadow(b) overlaps wf_extend(b+1) (they share no buffer)
     hipStream_t auxStream = nullptr;

@@ -61,6 +61,7 @@ struct WfArgs {
     uint32_t hasMedium;        // scene has thick transmissive materials (medium state travels with the path)
     uint32_t hasStochasticAlpha;
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
+    uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
     DeviceCounters* counters;
 };
 
@@ -220,9 +221,19 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
     unsigned int nRays = 0;
     const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
 
-    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.pathCnt[parity][seg], segBase = seg << a.segShift;
-        uint32_t next = 0;                       // wave-uniform: next ray of the segment to hand out
+    // The wave streams through its segments (gw, gw + totalWaves, ...) without draining between them: when one segment has been
+    // handed out completely the idle lanes refill from the next one, so only the very end of the wave's work runs with few lanes.
+    {
+        uint32_t seg = gw, cnt = 0, segBase = 0, next = 0;      // wave-uniform cursor: next ray of the current segment to hand out
+        bool haveSeg = false;
+        auto open_segment = [&]() {                             // first non-empty segment at or after `seg`
+            haveSeg = false; cnt = 0; next = 0;
+            for (; seg < a.numSegments; seg += totalWaves) {
+                cnt = a.b.pathCnt[parity][seg];
+                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+            }
+        };
+        open_segment();
         // per-lane traversal state
         bool active = false;
         Ray r; r.o = mk3(0.0f, 0.0f, 0.0f); r.d = mk3(0.0f, 0.0f, 1.0f); r.tmin = 0.0f; r.tmax = 1e10f;
@@ -231,10 +242,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
         Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
         int32_t cur = kTraversalDone; int sp = 0; uint32_t slot = 0, rng = 0, rng0 = 0; float tlim = 0.0f;
         for (;;) {
+            if (haveSeg && next >= cnt && (a.streamSegments || __ballot(active) == 0ull)) { seg += totalWaves; open_segment(); }
             // ---- refill idle lanes
             unsigned long long mIdle = __ballot(!active);
             uint32_t nIdle = (uint32_t)__popcll(mIdle);
-            if (next < cnt && (nIdle >= a.refillMin || nIdle == 64u)) {
+            if (haveSeg && (nIdle >= a.refillMin || nIdle == 64u)) {
                 uint32_t idx = next + prefix_rank(mIdle);
                 if (!active && idx < cnt) {
                     slot = segBase + idx;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                 }
                 next += nIdle;
             }
-            if (__ballot(active) == 0ull) break;
+            if (__ballot(active) == 0ull) { if (haveSeg) continue; break; }
             if (active) {
                 // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
                 while (cur >= 0) {
@@ -625,6 +637,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
     a.counters = counters;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
+    a.streamSegments = st.drainSegments ? 0u : 1u;
 
     // ---- kernel variants and grids
     int dev = 0; hipDeviceProp_t prop;
