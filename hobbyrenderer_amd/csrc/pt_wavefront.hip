@@ -324,17 +324,46 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     const uint32_t in = parity, out = parity ^ 1u;
     const SceneView& s = a.scene;
-    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.pathCnt[in][seg], segBase = seg << a.segShift;
-        uint32_t outCount = 0, shCount = 0;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            uint32_t i = base + lane;
-            bool valid = i < cnt, alive = false;
+    // The wave works through its segments (gw, gw + totalWaves, ...) as one stream of 64-lane iterations: when the open segment A
+    // has fewer than 64 entries left, the remaining lanes take the first entries of the next non-empty segment B, so only the wave's
+    // last iteration is partially filled (after compaction a 256-slot segment holds ~207 / 168 / 136 paths at bounces 1 / 2 / 3: one
+    // partly empty iteration per segment otherwise). Survivors and NEE entries still compact into their OWN segment (front of the
+    // out queue / shadow queue of A or B), so segments stay wave-owned and the layout deterministic.
+    {
+        uint32_t seg = gw, cnt = 0, segBase = 0, next = 0, outCount = 0, shCount = 0;   // segment A: cursor + output counters
+        bool haveSeg = false;
+        auto open_segment = [&]() {        // first non-empty segment at or after `seg`; empty ones get their (zero) counts written here
+            haveSeg = false; cnt = 0; next = 0; outCount = 0; shCount = 0;
+            for (; seg < a.numSegments; seg += totalWaves) {
+                cnt = a.b.pathCnt[in][seg];
+                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+                if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
+            }
+        };
+        open_segment();
+        while (haveSeg) {
+            // lanes [0, takeA) continue segment A; if A ends inside this iteration, lanes [takeA, takeA + takeB) start segment B
+            const uint32_t takeA = cnt - next < 64u ? cnt - next : 64u;
+            const uint32_t segA = seg, baseA = segBase, nextA = next;
+            const bool endsA = nextA + takeA >= cnt;
+            uint32_t takeB = 0, segB = 0, baseB = 0, cntB = 0;
+            if (endsA && takeA < 64u) {
+                uint32_t probe = seg + totalWaves;
+                for (; probe < a.numSegments; probe += totalWaves) {
+                    cntB = a.b.pathCnt[in][probe];
+                    if (cntB) break;
+                    if (lane == 0) { a.b.pathCnt[out][probe] = 0; a.b.shadowCnt[probe] = 0; }
+                }
+                if (probe < a.numSegments) { segB = probe; baseB = probe << a.segShift; takeB = cntB < 64u - takeA ? cntB : 64u - takeA; }
+                else segB = probe;          // no further segment: remembered so that the cursor below ends the loop
+            }
+            const bool inA = lane < takeA;
+            bool valid = lane < takeA + takeB, alive = false;
             uint32_t nNee = 0, smp = 0;
             PathState ps; f3 neeT = mk3(0.0f, 0.0f, 0.0f);
             NeeBuf<MAXL> nee; SurfaceCarry carry;
             if (valid) {
-                uint32_t slot = segBase + i;
+                uint32_t slot = inA ? baseA + nextA + lane : baseB + (lane - takeA);
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
                 ps.ray.o = mk3(o.x, o.y, o.z); ps.ray.d = mk3(d.x, d.y, d.z); ps.ray.tmin = o.w; ps.ray.tmax = 1e10f;
@@ -372,10 +401,10 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                 }
                 if (lastBounce) alive = false;
             }
-            // ---- wave-local compaction of survivors into the out queue
-            unsigned long long m = __ballot(alive);
+            // ---- wave-local compaction of survivors into the out queue of their own segment
+            const unsigned long long mA = __ballot(alive && inA), mB = __ballot(alive && !inA);
             if (alive) {
-                uint32_t o = segBase + outCount + prefix_rank(m);
+                uint32_t o = inA ? baseA + outCount + prefix_rank(mA) : baseB + prefix_rank(mB);
                 a.b.rayO[out][o] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tmin);
                 a.b.rayD[out][o] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.rng));
                 a.b.thr[out][o] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, __uint_as_float(smp));
@@ -384,11 +413,10 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                     a.b.med1[out][o] = make_float4(ps.sigmaS.x, ps.sigmaS.y, ps.sigmaS.z, ps.inVolume ? 1.0f : 0.0f);
                 }
             }
-            outCount += (uint32_t)__popcll(m);
-            // ---- wave-local compaction of NEE work into the shadow queue
-            unsigned long long ms = __ballot(nNee > 0);
+            // ---- wave-local compaction of NEE work into the shadow queue of their own segment
+            const unsigned long long msA = __ballot(nNee > 0 && inA), msB = __ballot(nNee > 0 && !inA);
             if (nNee > 0) {
-                uint32_t e = segBase + shCount + prefix_rank(ms);
+                uint32_t e = inA ? baseA + shCount + prefix_rank(msA) : baseB + prefix_rank(msB);
                 a.b.sh0[e] = make_float4(carry.worldPos.x, carry.worldPos.y, carry.worldPos.z, __uint_as_float(smp));
                 a.b.sh1[e] = make_float4(carry.N.x, carry.N.y, carry.N.z, carry.roughness);
                 a.b.sh2[e] = make_float4(carry.V.x, carry.V.y, carry.V.z, carry.metallic);
@@ -398,9 +426,23 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                 for (int j = 0; j < MAXL; ++j)
                     if ((uint32_t)j < nNee) a.b.shL[(size_t)e * a.maxLights + j] = make_float4(nee.ux[j], nee.uy[j], __uint_as_float(nee.light[j]), 0.0f);
             }
-            shCount += (uint32_t)__popcll(ms);
+            // ---- advance the cursor
+            outCount += (uint32_t)__popcll(mA); shCount += (uint32_t)__popcll(msA);
+            if (!endsA) next = nextA + takeA;
+            else {
+                if (lane == 0) { a.b.pathCnt[out][segA] = outCount; a.b.shadowCnt[segA] = shCount; }
+                if (takeB) {                 // B becomes the open segment, already takeB entries in
+                    seg = segB; segBase = baseB; cnt = cntB; next = takeB;
+                    outCount = (uint32_t)__popcll(mB); shCount = (uint32_t)__popcll(msB);
+                    haveSeg = true;
+                    if (next >= cnt) {       // B was short enough to end in the same iteration
+                        if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
+                        seg += totalWaves; open_segment();
+                    }
+                } else if (takeA < 64u) { seg = segB; haveSeg = false; }     // probed to the end: nothing left
+                else { seg += totalWaves; open_segment(); }
+            }
         }
-        if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
     }
 }
 
@@ -422,12 +464,8 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nRays = 0;
-    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            uint32_t i = base + lane;
-            if (i < cnt) {
-                uint32_t e = segBase + i;
+    // one shadow-queue entry: every light sample of one path vertex
+    auto process = [&](uint32_t e) {
                 float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], h4 = a.b.sh4[e];
                 f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), T = mk3(h4.x, h4.y, h4.z);
                 uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
@@ -462,10 +500,39 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     r.x = r.x + term.x; r.y = r.y + term.y; r.z = r.z + term.z;
                     a.b.radiance[smp] = r;
                 }
+    };
+    if (NONOPAQUE) {
+        // Buffered variant (long, uneven entries): the wave hands out the entries of its segments (gw, gw + totalWaves, ...) as one
+        // stream, an iteration whose segment runs out continues with the next one, so only the wave's last iteration is partly filled
+        // (-4 % on configs 4 / 5). The short opaque any-hit variant below is faster with the plain per-segment loop (config 2).
+        uint32_t seg = gw, cnt = 0, segBase = 0, next = 0; bool haveSeg = false;
+        auto open_segment = [&]() {
+            haveSeg = false; cnt = 0; next = 0;
+            for (; seg < a.numSegments; seg += totalWaves) {
+                cnt = a.b.shadowCnt[seg];
+                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+            }
+        };
+        open_segment();
+        while (haveSeg) {
+            uint32_t e = 0xFFFFFFFFu, filled = 0;
+            while (filled < 64u && haveSeg) {
+                uint32_t take = cnt - next < 64u - filled ? cnt - next : 64u - filled;
+                if (lane >= filled && lane < filled + take) e = segBase + next + (lane - filled);
+                next += take; filled += take;
+                if (next >= cnt) { seg += totalWaves; open_segment(); }
+            }
+            if (e != 0xFFFFFFFFu) process(e);
+        }
+    } else {
+        for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+            const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                uint32_t i = base + lane;
+                if (i < cnt) process(segBase + i);
             }
         }
     }
-    (void)lane;
     block_count_add(&a.counters->closestRays, 1, nRays);
 }
 

@@ -8,7 +8,7 @@ import numpy as np
 from . import structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhobbyrt_pt.so")
+LIB_PATH = os.environ.get("HRPT_LIBRARY") or os.path.join(_HERE, "libhobbyrt_pt.so")   # HRPT_LIBRARY: A/B another build of the same ABI
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
