@@ -281,7 +281,15 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     Box root;
     int32_t r = b.build(0, (uint32_t)tris.size(), 0, root);
     if (r < 0) { out.rootLeaf = r; out.nodes.clear(); }
-    else { out.nodes4.reserve(out.nodes.size() / 2 + 1); collapse4(out.nodes, 0, out.nodes4, 0, out.maxDepth4); }
+    else {
+        out.nodes4.reserve(out.nodes.size() / 2 + 1); collapse4(out.nodes, 0, out.nodes4, 0, out.maxDepth4);
+        double sum = 0.0;
+        auto area = [](const float* mn, const float* mx) { double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; return dx * dy + dy * dz + dz * dx; };
+        for (const HostNode& n : out.nodes)
+            sum += area(n.lmin, n.lmax) * (n.left >= 0 ? 1.0 : (double)(((uint32_t)~n.left & 3u) + 1u)) + area(n.rmin, n.rmax) * (n.right >= 0 ? 1.0 : (double)(((uint32_t)~n.right & 3u) + 1u));
+        double ra = root.area() * 0.5;
+        out.sahCost = ra > 0.0 ? (float)(1.0 + sum / ra) : 0.0f;
+    }
 
     // shading attributes in leaf order
     const bool needTangents = scene_needs_tangents(s);

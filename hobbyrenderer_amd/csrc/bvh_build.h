@@ -65,6 +65,7 @@ struct BuiltBvh {
     std::vector<HostInstShade> instShade; // per instance
     int32_t rootLeaf = 0;           // encoded leaf when nodes is empty and tris is not
     uint32_t maxDepth = 0;
+    float sahCost = 0.0f;           // SAH cost of the 2-wide tree (node cost 1, triangle cost 1), root area = 1
 };
 
 constexpr uint32_t kMaxLeafTris = 4;

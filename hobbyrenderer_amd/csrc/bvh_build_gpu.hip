@@ -15,6 +15,7 @@ using std::memset;   // rocprim/iterator/texture_cache_iterator.hpp calls an unq
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,6 +44,10 @@ struct BuildBuffers {
     uint32_t* keep; uint32_t* newIndex;         // kept (range > 4) internal nodes -> dense BVH2 index
     uint32_t* keptParent; uint32_t* depth;      // per dense BVH2 node
     uint32_t* even; uint32_t* index4;           // per dense BVH2 node: even depth -> BVH4 node index
+    // PLOC: node pool of 2n entries (0..n-1 leaves in Morton order, n + c = c-th merged node), cluster lists, per-iteration scratch
+    float4* pMin; float4* pMax; uint32_t* pSize; uint32_t* pParent; uint32_t* pL; uint32_t* pR;
+    uint32_t* clusterA; uint32_t* clusterB; uint32_t* nn; uint32_t* mergeFlag; uint32_t* validFlag; uint32_t* mergeIdx; uint32_t* validIdx;
+    uint32_t* finalPos;
     // outputs
     GpuNode* nodes; GpuNode4* nodes4; GpuTri* tris; GpuTriAttr* attrs; GpuTriTangent* tangents;
 };
@@ -199,12 +204,94 @@ __global__ __launch_bounds__(kB) void k_fit(BuildBuffers b)
     }
 }
 
+// ---- 3b/4b. PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) instead of the radix tree: clusters in Morton order
+// repeatedly merge with their nearest neighbour (smallest surface area of the joint box) inside a window of +-kPlocRadius positions
+// when the choice is mutual. Quality close to a top-down SAH build at a small multiple of the LBVH cost.
+constexpr int kPlocRadius = 16;
+__device__ __forceinline__ float union_area(float4 amn, float4 amx, float4 bmn, float4 bmx)
+{
+    float dx = fmaxf(amx.x, bmx.x) - fminf(amn.x, bmn.x), dy = fmaxf(amx.y, bmx.y) - fminf(amn.y, bmn.y), dz = fmaxf(amx.z, bmx.z) - fminf(amn.z, bmn.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(kB) void k_ploc_init(BuildBuffers b)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= b.triCount) return;
+    uint32_t g = b.valB[k];
+    b.pMin[k] = b.boxMinU[g]; b.pMax[k] = b.boxMaxU[g]; b.pSize[k] = 1u; b.pParent[k] = 0xFFFFFFFFu;
+    b.clusterA[k] = k;
+}
+__global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* __restrict__ cluster, uint32_t count)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= count) return;
+    uint32_t me = cluster[i];
+    float4 mn = b.pMin[me], mx = b.pMax[me];
+    int lo = (int)i - kPlocRadius < 0 ? 0 : (int)i - kPlocRadius, hi = (int)i + kPlocRadius >= (int)count ? (int)count - 1 : (int)i + kPlocRadius;
+    float best = 3e38f; uint32_t bestJ = i;
+    for (int j = lo; j <= hi; ++j) {
+        if (j == (int)i) continue;
+        uint32_t o = cluster[j];
+        float a = union_area(mn, mx, b.pMin[o], b.pMax[o]);
+        if (a < best) { best = a; bestJ = (uint32_t)j; }       // ties keep the smaller index: makes mutual pairs well defined
+    }
+    b.nn[i] = bestJ;
+}
+__global__ __launch_bounds__(kB) void k_ploc_flags(BuildBuffers b, uint32_t count)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= count) return;
+    uint32_t j = b.nn[i];
+    bool mutual = j != i && b.nn[j] == i;
+    b.mergeFlag[i] = (mutual && i < j) ? 1u : 0u;
+    b.validFlag[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ __launch_bounds__(kB) void k_ploc_apply(BuildBuffers b, const uint32_t* __restrict__ cluster, uint32_t* __restrict__ clusterOut, uint32_t count, uint32_t created)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= count || !b.validFlag[i]) return;
+    uint32_t pos = b.validIdx[i], me = cluster[i];
+    if (b.mergeFlag[i]) {
+        uint32_t other = cluster[b.nn[i]];
+        uint32_t id = b.triCount + created + b.mergeIdx[i];            // deterministic: creation order = position order within the iteration
+        float4 amn = b.pMin[me], amx = b.pMax[me], bmn = b.pMin[other], bmx = b.pMax[other];
+        b.pMin[id] = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.0f);
+        b.pMax[id] = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.0f);
+        b.pL[id] = me; b.pR[id] = other; b.pSize[id] = b.pSize[me] + b.pSize[other]; b.pParent[id] = 0xFFFFFFFFu;
+        b.pParent[me] = id; b.pParent[other] = id;
+        clusterOut[pos] = id;
+    } else clusterOut[pos] = me;
+}
+// position of the first primitive of every pool node in depth-first order (left subtree first): sum of the left siblings' sizes on the way up
+__global__ __launch_bounds__(kB) void k_ploc_offsets(BuildBuffers b)
+{
+    uint32_t v = blockIdx.x * kB + threadIdx.x;
+    uint32_t total = 2u * b.triCount - 1u;
+    if (v >= total) return;
+    uint32_t off = 0, node = v;
+    for (uint32_t p = b.pParent[node]; p != 0xFFFFFFFFu; p = b.pParent[p]) { if (b.pR[p] == node) off += b.pSize[b.pL[p]]; node = p; }
+    b.finalPos[v] = off;
+}
+// hand the PLOC tree to the common back end: internal node c becomes radix-tree style node (n-2) - c (the root, created last, is 0)
+__global__ __launch_bounds__(kB) void k_ploc_finish(BuildBuffers b, uint32_t* __restrict__ orderOut)
+{
+    uint32_t v = blockIdx.x * kB + threadIdx.x;
+    const uint32_t n = b.triCount;
+    if (v >= 2u * n - 1u) return;
+    if (v < n) { orderOut[b.finalPos[v]] = b.valB[v]; return; }          // triangles in depth-first leaf order
+    uint32_t c = v - n, id = (n - 2u) - c;
+    auto ref = [&](uint32_t child) { return child < n ? (b.finalPos[child] | kLeafBit) : (n - 2u) - (child - n); };
+    b.childL[id] = ref(b.pL[v]); b.childR[id] = ref(b.pR[v]);
+    b.nodeMin[id] = b.pMin[v]; b.nodeMax[id] = b.pMax[v];
+    b.rangeFirst[id] = b.finalPos[v]; b.rangeLast[id] = b.finalPos[v] + b.pSize[v] - 1u;
+}
+
 // ---- 5. leaves of up to 4 triangles: an internal node stays inner iff its range holds more than kMaxLeafTris primitives
-__global__ __launch_bounds__(kB) void k_classify(BuildBuffers b)
+__global__ __launch_bounds__(kB) void k_classify(BuildBuffers b, uint32_t maxLeaf)
 {
     uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i + 1 >= b.triCount) return;
-    b.keep[i] = (b.rangeLast[i] - b.rangeFirst[i] + 1u > 4u) ? 1u : 0u;
+    b.keep[i] = (b.rangeLast[i] - b.rangeFirst[i] + 1u > maxLeaf) ? 1u : 0u;
 }
 
 __device__ __forceinline__ int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1u)); }
@@ -253,6 +340,21 @@ __global__ __launch_bounds__(kB) void k_depth(BuildBuffers b, uint32_t nodeCount
     uint32_t m = d;
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(&b.flags[1], m);
+}
+
+// ---- 7b. SAH cost of the dense BVH2 (traversal cost 1, intersection cost 1 per triangle), relative to the root's surface area
+__global__ __launch_bounds__(kB) void k_sah(BuildBuffers b, uint32_t nodeCount, float* __restrict__ costOut)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    float c = 0.0f;
+    if (k < nodeCount) {
+        GpuNode n = b.nodes[k];
+        auto area = [](const float* mn, const float* mx) { float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; return dx * dy + dy * dz + dz * dx; };
+        float al = area(n.lmin, n.lmax), ar = area(n.rmin, n.rmax);
+        c = al * (n.left >= 0 ? 1.0f : (float)(((uint32_t)~n.left & 3u) + 1u)) + ar * (n.right >= 0 ? 1.0f : (float)(((uint32_t)~n.right & 3u) + 1u));
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(costOut, c);
 }
 
 // ---- 8. 4-wide collapse: every even-depth node absorbs its inner children (two BVH2 levels per BVH4 level)
@@ -346,7 +448,7 @@ struct Arena {          // one temporary allocation carved into aligned pieces
 
 } // namespace
 
-hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32_t maxStackDepth, const std::function<void*(size_t)>& sceneAlloc,
+hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool usePloc, uint32_t maxStackDepth, const std::function<void*(size_t)>& sceneAlloc,
                                hipStream_t stream, GpuBuiltBvh& out, std::string& error)
 {
     out = GpuBuiltBvh();
@@ -387,6 +489,10 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32
         b.nodeMin = A.take<float4>(n); b.nodeMax = A.take<float4>(n);
         b.keep = A.take<uint32_t>(n); b.newIndex = A.take<uint32_t>(n); b.keptParent = A.take<uint32_t>(n); b.depth = A.take<uint32_t>(n);
         b.even = A.take<uint32_t>(n); b.index4 = A.take<uint32_t>(n);
+        b.pMin = A.take<float4>(2 * (size_t)n); b.pMax = A.take<float4>(2 * (size_t)n); b.pSize = A.take<uint32_t>(2 * (size_t)n); b.pParent = A.take<uint32_t>(2 * (size_t)n);
+        b.pL = A.take<uint32_t>(2 * (size_t)n); b.pR = A.take<uint32_t>(2 * (size_t)n); b.finalPos = A.take<uint32_t>(2 * (size_t)n);
+        b.clusterA = A.take<uint32_t>(n); b.clusterB = A.take<uint32_t>(n); b.nn = A.take<uint32_t>(n); b.mergeFlag = A.take<uint32_t>(n); b.validFlag = A.take<uint32_t>(n);
+        b.mergeIdx = A.take<uint32_t>(n); b.validIdx = A.take<uint32_t>(n);
         b.nodes = A.take<GpuNode>(n);            // staging: the dense count is known only after the scan
         b.nodes4 = A.take<GpuNode4>(n / 2 + 1);
         prim = A.take<char>(std::max(sortBytes, scanBytes));
@@ -418,17 +524,46 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32
     hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
     hipLaunchKernelGGL(k_morton, gT, blk, 0, stream, b);
     if ((e = rocprim::radix_sort_pairs(prim, sortBytes, b.keyA, b.keyB, b.valA, b.valB, n, 0, 63, stream)) != hipSuccess) return fail(e, "rocprim::radix_sort_pairs");
-    // Hierarchy with the full 63-bit codes first; when the tree is deeper than the traversal stacks allow, drop low Morton bits
-    // (no re-sort: the order stays the full-code order) until it fits.
-    uint32_t nodeCount = 0, maxDepthSeen = 0; int usedBits = 0;
-    const int bitBudgets[] = { 63, 48, 39, 30, 21, 12, 0 };
-    for (int budget : bitBudgets) {
-        const int shift = 63 - budget;
-        (void)hipMemsetAsync(b.visit, 0, (size_t)n * 4, stream);
+    // Hierarchy attempts, best tree first: PLOC (when asked for), then the radix tree over the full 63-bit codes, then radix trees over
+    // fewer Morton bits (no re-sort: the order stays the full-code order) until the depth fits the traversal stacks.
+    uint32_t nodeCount = 0, maxDepthSeen = 0; int usedBits = 0; bool usedPloc = false;
+    uint32_t maxLeafTris = 4;
+    if (const char* e = getenv("HRPT_GPU_BVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) maxLeafTris = (uint32_t)v; }
+    const int attempts[] = { 64, 63, 48, 39, 30, 21, 12, 0 };          // 64 = PLOC
+    uint32_t* const mortonOrder = b.valB;                              // leaf k of the radix tree = triangle mortonOrder[k]
+    for (int budget : attempts) {
+        if (budget == 64) {
+            if (!usePloc) continue;
+            hipLaunchKernelGGL(k_ploc_init, gT, blk, 0, stream, b);
+            uint32_t count = n, created = 0; uint32_t* cur = b.clusterA; uint32_t* nxt = b.clusterB; bool ok = true;
+            while (count > 1) {
+                const dim3 gC((count + kB - 1) / kB);
+                hipLaunchKernelGGL(k_ploc_nn, gC, blk, 0, stream, b, cur, count);
+                hipLaunchKernelGGL(k_ploc_flags, gC, blk, 0, stream, b, count);
+                if ((e = rocprim::exclusive_scan(prim, scanBytes, b.mergeFlag, b.mergeIdx, 0u, count, rocprim::plus<uint32_t>(), stream)) != hipSuccess ||
+                    (e = rocprim::exclusive_scan(prim, scanBytes, b.validFlag, b.validIdx, 0u, count, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(PLOC)");
+                hipLaunchKernelGGL(k_ploc_apply, gC, blk, 0, stream, b, cur, nxt, count, created);
+                uint32_t tail[2] = { 0, 0 };
+                if ((e = hipMemcpyAsync(&tail[0], b.mergeIdx + (count - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+                    (e = hipMemcpyAsync(&tail[1], b.mergeFlag + (count - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+                    (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (PLOC iteration)");
+                const uint32_t merges = tail[0] + tail[1];
+                if (merges == 0 || merges >= count) { ok = false; break; }      // cannot happen with mutual nearest neighbours; never loop forever
+                created += merges; count -= merges; std::swap(cur, nxt);
+            }
+            if (!ok || created != n - 1) continue;
+            hipLaunchKernelGGL(k_ploc_offsets, dim3((2 * n - 1 + kB - 1) / kB), blk, 0, stream, b);
+            hipLaunchKernelGGL(k_ploc_finish, dim3((2 * n - 1 + kB - 1) / kB), blk, 0, stream, b, b.valA);
+            b.valB = b.valA;                                           // depth-first leaf order replaces the Morton order downstream
+        } else {
+            const int shift = 63 - budget;
+            b.valB = mortonOrder;
+            (void)hipMemsetAsync(b.visit, 0, (size_t)n * 4, stream);
+            hipLaunchKernelGGL(k_hierarchy, gT, blk, 0, stream, b, shift);
+            hipLaunchKernelGGL(k_fit, gT, blk, 0, stream, b);
+        }
         (void)hipMemsetAsync(b.flags + 1, 0, 4, stream);
-        hipLaunchKernelGGL(k_hierarchy, gT, blk, 0, stream, b, shift);
-        hipLaunchKernelGGL(k_fit, gT, blk, 0, stream, b);
-        hipLaunchKernelGGL(k_classify, gT, blk, 0, stream, b);
+        hipLaunchKernelGGL(k_classify, gT, blk, 0, stream, b, maxLeafTris);
         if ((e = rocprim::exclusive_scan(prim, scanBytes, b.keep, b.newIndex, 0u, n - 1, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(keep)");
         hipLaunchKernelGGL(k_emit2, gT, blk, 0, stream, b);
         // dense node count = newIndex[n-2] + keep[n-2]
@@ -441,15 +576,20 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32
         hipLaunchKernelGGL(k_depth, dim3((nodeCount + kB - 1) / kB), blk, 0, stream, b, nodeCount);
         uint32_t d = 0;
         if ((e = hipMemcpyAsync(&d, b.flags + 1, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess || (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (depth)");
-        maxDepthSeen = d; usedBits = budget;
+        maxDepthSeen = d; usedBits = budget == 64 ? 63 : budget; usedPloc = budget == 64;
         if (d + 2 <= maxStackDepth) break;
     }
     const dim3 gN((nodeCount + kB - 1) / kB);
     if ((e = rocprim::exclusive_scan(prim, scanBytes, b.even, b.index4, 0u, nodeCount, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(even)");
     hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount);
+    float* sahDev = reinterpret_cast<float*>(b.flags + 4);
+    (void)hipMemsetAsync(sahDev, 0, 4, stream);
+    hipLaunchKernelGGL(k_sah, gN, blk, 0, stream, b, nodeCount, sahDev);
     hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
-    uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 };
+    uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 }; float sahSum = 0.0f; GpuNode rootNode;
     if ((e = hipMemcpyAsync(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&sahSum, sahDev, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&rootNode, b.nodes, sizeof rootNode, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (e = hipMemcpyAsync(&tail4[0], b.index4 + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (e = hipMemcpyAsync(&tail4[1], b.even + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (emit)");
@@ -468,7 +608,14 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, uint32
 
     out.nodes = nodes; out.nodeCount = nodeCount; out.nodes4 = nodes4; out.node4Count = node4Count;
     out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n;
-    out.maxDepth = maxDepthSeen; out.maxDepth4 = maxDepthSeen / 2; out.mortonBits = (uint32_t)usedBits; out.deviceMs = ms;
+    {   // root box = union of the root's two child boxes
+        float dx = std::max(rootNode.lmax[0], rootNode.rmax[0]) - std::min(rootNode.lmin[0], rootNode.rmin[0]);
+        float dy = std::max(rootNode.lmax[1], rootNode.rmax[1]) - std::min(rootNode.lmin[1], rootNode.rmin[1]);
+        float dz = std::max(rootNode.lmax[2], rootNode.rmax[2]) - std::min(rootNode.lmin[2], rootNode.rmin[2]);
+        float ra = dx * dy + dy * dz + dz * dx;
+        out.sahCost = ra > 0.0f ? 1.0f + sahSum / ra : 0.0f;
+    }
+    out.maxDepth = maxDepthSeen; out.maxDepth4 = maxDepthSeen / 2; out.mortonBits = (uint32_t)usedBits; out.ploc = usedPloc; out.deviceMs = ms;
     return hipSuccess;
 }
 

@@ -127,7 +127,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
-    if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "gpu") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : HRPT_BVH_BUILDER_HOST_SAH;
+    if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "ploc") == 0 || strcmp(e, "2") == 0) ? HRPT_BVH_BUILDER_GPU_PLOC : ((strcmp(e, "gpu") == 0 || strcmp(e, "lbvh") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : HRPT_BVH_BUILDER_HOST_SAH);
     if (const char* e = getenv("HRPT_WF_PAD_LDS")) c->wf.padLdsBytes = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_DRAIN_SEGMENTS")) c->wf.drainSegments = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
@@ -183,17 +183,17 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     int r;
     uint32_t maxDepth = 0, maxDepth4 = 0;
     bool built = false;
-    if (c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH && sceneTris >= 8) {
+    if ((c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH || c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC) && sceneTris >= 8) {
         // the whole build runs on the device; only the per-instance adjugate rows (O(instances)) are prepared on the host
         GpuBuiltBvh g; std::string gerr;
         size_t mark = c->allocations.size();
         auto sceneAlloc = [c](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; c->allocations.push_back(p); return p; };
-        hipError_t ge = build_scene_bvh_gpu(*s, scene_needs_tangents(*s), kTraversalStackDepth, sceneAlloc, c->stream, g, gerr);
+        hipError_t ge = build_scene_bvh_gpu(*s, scene_needs_tangents(*s), c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, sceneAlloc, c->stream, g, gerr);
         if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
             v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
             v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
             maxDepth = g.maxDepth; maxDepth4 = g.maxDepth4; built = true;
-            c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits;
+            c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits; c->buildInfo.sahCost = g.sahCost;
         } else {
             // too deep for the traversal stacks (or a device error): drop what was allocated and build on the host instead
             for (size_t i = mark; i < c->allocations.size(); ++i) (void)hipFree(c->allocations[i]);
@@ -234,7 +234,7 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // the BuiltBvh staging vectors die at scope exit
         maxDepth = bvh.maxDepth; maxDepth4 = bvh.maxDepth4;
-        c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH;
+        c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.sahCost = bvh.sahCost;
     }
     c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = v.nodeCount; c->buildInfo.node4Count = v.node4Count;
@@ -512,7 +512,7 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
 int hrpt_set_bvh_builder(HrptContext* c, int builder)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
-    if (builder != HRPT_BVH_BUILDER_HOST_SAH && builder != HRPT_BVH_BUILDER_GPU_LBVH) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_bvh_builder: unknown builder");
+    if (builder != HRPT_BVH_BUILDER_HOST_SAH && builder != HRPT_BVH_BUILDER_GPU_LBVH && builder != HRPT_BVH_BUILDER_GPU_PLOC) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_bvh_builder: unknown builder");
     c->bvhBuilder = builder;
     return HRPT_OK;
 }

@@ -102,10 +102,10 @@ RAYS_CLOSEST, RAYS_SHADOW, RAYS_DEVICE_POINTERS = 0, 1, 0x100
 class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
     _fields_ = [("requestedBuilder", C.c_uint32), ("usedBuilder", C.c_uint32), ("buildMs", C.c_float), ("deviceBuildMs", C.c_float),
                 ("triangleCount", C.c_uint32), ("nodeCount", C.c_uint32), ("node4Count", C.c_uint32), ("maxDepth", C.c_uint32),
-                ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("pad", C.c_uint32 * 2)]
+                ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("pad", C.c_uint32 * 1)]
 
 
-BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH = 0, 1
+BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC = 0, 1, 2
 
 
 def default_material():

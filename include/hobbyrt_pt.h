@@ -268,7 +268,9 @@ int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output
  * rebuilt scenes). Radiance is identical either way (the hit definition is BVH-independent). The GPU builder falls back
  * to the host one for scenes under 8 triangles or when its tree is deeper than the traversal stacks allow. */
 #define HRPT_BVH_BUILDER_HOST_SAH 0
-#define HRPT_BVH_BUILDER_GPU_LBVH 1
+#define HRPT_BVH_BUILDER_GPU_LBVH 1      /* Morton radix tree (Karras 2012): fastest build */
+#define HRPT_BVH_BUILDER_GPU_PLOC 2      /* Morton order + nearest-neighbour clustering (PLOC): better tree, a few times the LBVH build time;
+                                            falls back to the LBVH hierarchy when its tree is too deep for the traversal stacks */
 int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene */
 typedef struct HrptBuildInfo {
     uint32_t requestedBuilder, usedBuilder;     /* HRPT_BVH_BUILDER_* */
@@ -276,7 +278,8 @@ typedef struct HrptBuildInfo {
     float    deviceBuildMs;                     /* GPU builder: device time, first kernel to last node copy; else 0 */
     uint32_t triangleCount, nodeCount, node4Count, maxDepth, maxDepth4;
     uint32_t mortonBits;                        /* GPU builder: Morton bits of the hierarchy (63 unless the full-code tree was too deep) */
-    uint32_t pad[2];
+    float    sahCost;                           /* surface-area-heuristic cost of the 2-wide tree: 1 + sum(area(child) * (inner ? 1 : triangles)) / area(root) */
+    uint32_t pad[1];
 } HrptBuildInfo;                                /* 48 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
 

@@ -11,7 +11,7 @@ for name, mk in cases:
     sc, view, pos, cfg = mk()
     cb = scenes.fill_constants(view, pos, sc, 0, 4)
     ref = None
-    for builder, bname in ((S.BVH_BUILDER_HOST_SAH, "host SAH"), (S.BVH_BUILDER_GPU_LBVH, "gpu LBVH")):
+    for builder, bname in ((S.BVH_BUILDER_HOST_SAH, "host SAH"), (S.BVH_BUILDER_GPU_LBVH, "gpu LBVH"), (S.BVH_BUILDER_GPU_PLOC, "gpu PLOC")):
         c = native.PathTracerContext(0); c.set_bvh_builder(builder); c.resize(1920, 1080)
         ups = []
         for r in range(3):
@@ -23,6 +23,6 @@ for name, mk in cases:
         acc = c.read_accumulation()
         if ref is None: ref = acc
         same = np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
-        print(f"{name:28s} {bname:9s} used={bi.usedBuilder} tris={bi.triangleCount} nodes={bi.nodeCount} nodes4={bi.node4Count} depth={bi.maxDepth}/{bi.maxDepth4} bits={bi.mortonBits} "
+        print(f"{name:28s} {bname:9s} used={bi.usedBuilder} tris={bi.triangleCount} nodes={bi.nodeCount} nodes4={bi.node4Count} depth={bi.maxDepth}/{bi.maxDepth4} bits={bi.mortonBits} sah={bi.sahCost:.1f} "
               f"upload_ms={min(ups):.1f} build_ms={bi.buildMs:.1f} device_build_ms={bi.deviceBuildMs:.2f} frame_ms={np.median(t[1:]):.2f} same_image={same}", flush=True)
         c.close()

@@ -176,30 +176,31 @@ def test_forced_bvh_width(luts, width, monkeypatch):
 
 
 # ---- GPU-built acceleration structure: same radiance bits as with the host SAH build ----------
-def _gpu_built(luts, sc, view, pos, w, h, spp, bounces, flags=S.FRAME_DEFAULT):
+def _gpu_built(luts, sc, view, pos, w, h, spp, bounces, flags=S.FRAME_DEFAULT, builder=S.BVH_BUILDER_GPU_LBVH):
     from hobbyrenderer_amd.native import PathTracerContext
     c = PathTracerContext(0)
     try:
-        c.set_bvh_builder(S.BVH_BUILDER_GPU_LBVH)
+        c.set_bvh_builder(builder)
         res = _run_both(c, sc, view, pos, w, h, spp, bounces, flags)
         return res, c.build_info()
     finally:
         c.close()
 
 
+@pytest.mark.parametrize("builder", [S.BVH_BUILDER_GPU_LBVH, S.BVH_BUILDER_GPU_PLOC], ids=["lbvh", "ploc"])
 @pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
-def test_gpu_bvh_builder_parity(luts, flags):
+def test_gpu_bvh_builder_parity(luts, flags, builder):
     sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54)                       # 38 triangles: LDS-resident tree
-    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
-    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH and bi.triangleCount == 38 and bi.nodeCount > 0 and bi.node4Count > 0
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags, builder)
+    assert bi.usedBuilder == builder and bi.triangleCount == 38 and bi.nodeCount > 0 and bi.node4Count > 0
     _assert_parity(*res)
     sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)              # non-opaque candidates, media
-    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
-    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags, builder)
+    assert bi.usedBuilder == builder
     _assert_parity(*res)
     sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=1.0, tex_size=32)   # ~100 k triangles, textures + tangents, global tree
-    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags)
-    assert bi.usedBuilder == S.BVH_BUILDER_GPU_LBVH and bi.triangleCount > 90000 and bi.deviceBuildMs > 0
+    res, bi = _gpu_built(luts, sc, view, pos, 96, 54, 2, cfg["max_bounces"], flags, builder)
+    assert bi.usedBuilder in (builder, S.BVH_BUILDER_GPU_LBVH) and bi.triangleCount > 90000 and bi.deviceBuildMs > 0
     assert bi.maxDepth + 2 <= 32 and 3 * bi.maxDepth4 + 2 <= 64
     _assert_parity(*res)
 
@@ -223,6 +224,9 @@ def test_gpu_bvh_builder_small_and_degenerate(luts):
         sc = b.finalize(luts)
         _assert_parity(*_run_both(c, sc, view, pos, 32, 32, 1, 3, S.FRAME_DEFAULT))
         assert c.build_info().usedBuilder == S.BVH_BUILDER_GPU_LBVH
+        c.set_bvh_builder(S.BVH_BUILDER_GPU_PLOC)          # coincident boxes: every pairing ties, the index tie-break keeps pairs mutual
+        _assert_parity(*_run_both(c, sc, view, pos, 32, 32, 1, 3, S.FRAME_DEFAULT))
+        assert c.build_info().usedBuilder in (S.BVH_BUILDER_GPU_PLOC, S.BVH_BUILDER_GPU_LBVH)
         with pytest.raises(Exception):
             c.set_bvh_builder(7)
     finally:
