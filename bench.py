@@ -43,6 +43,20 @@ def _pmc_traffic(kernel):
         return None
 
 
+def _pmc_valu(kernel):
+    """VALU-issue counters of `kernel` on config 2 from the committed rocprofv3 --pmc passes (profiles/r*_pmc_valu_config2.json):
+    the kernels of this path are VALU-issue-bound, so these say more about them than the HBM fraction does."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_config2.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,7 +271,8 @@ def main():
             kernel_times = None
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": _pmc_traffic(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None, "kernel": kernel, "kernels": kernel_times, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                              "traffic": _pmc_traffic(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None,
+                              "valu": _pmc_valu(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None, "kernel": kernel, "kernels": kernel_times, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                               "algorithmic_bytes_per_launch": per_launch_bytes,
                               "bytes_per_closest_ray": b_closest, "bytes_per_shadow_ray": b_shadow,
                               "whole_step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
