@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -27,6 +28,8 @@ struct Box {
 };
 
 struct Builder {
+    uint32_t minLeaf = 2;       // ranges this small always become a leaf
+    float triCost = 1.0f;       // SAH: cost of a triangle test relative to a node step
     std::vector<Prim> prims;
     const std::vector<HostTri>* src = nullptr;
     BuiltBvh* out = nullptr;
@@ -47,14 +50,14 @@ struct Builder {
         Box b, cb;
         for (uint32_t i = first; i < first + count; ++i) { b.grow(prims[i].bmin, prims[i].bmax); cb.grow(prims[i].c, prims[i].c); }
         bounds = b;
-        if (count <= 2) return make_leaf(first, count);
+        if (count <= minLeaf) return make_leaf(first, count);
 
         uint32_t log2c = 0; while ((1u << log2c) < count) ++log2c;
         bool forceMedian = depth + log2c + 2 >= kTraversalStackDepth;
 
         int bestAxis = -1; uint32_t bestSplit = 0; float bestCost = 1e30f;
         constexpr int NB = 16;
-        float leafCost = (float)count * b.area();
+        float leafCost = triCost * (float)count * b.area();
         if (!forceMedian) {
             for (int axis = 0; axis < 3; ++axis) {
                 float lo = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
@@ -265,6 +268,8 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     if (tris.empty()) return true;
 
     Builder b; b.src = &tris; b.out = &out;
+    if (const char* e = getenv("HRPT_HOST_BVH_MIN_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) b.minLeaf = (uint32_t)v; }
+    if (const char* e = getenv("HRPT_HOST_BVH_TRI_COST")) { float v = (float)atof(e); if (v > 0.0f) b.triCost = v; }
     b.prims.resize(tris.size());
     for (size_t i = 0; i < tris.size(); ++i) {
         Prim& p = b.prims[i]; const HostTri& t = tris[i];

@@ -662,7 +662,144 @@ void Scene::SetCameraFromSceneCamera(const Camera& sceneCamera)
 
 } // namespace hobbyrt
 
+namespace {
+
+// ---------------------------------------------------------------- .scene.json (src/SceneLoader.cpp:184-576)
+float jfloat(const json::Value& v) { return v.f32_direct(0.0f); }                      // json_get_float: std::stof of the token, 0 on failure
+Vector3 jvec3(const json::Value& v) { return Vector3(jfloat(v[0]), jfloat(v[1]), jfloat(v[2])); }
+Quaternion jquat(const json::Value& v)
+{   // json_get_quat (:94-112): a one-element array [0] means "no rotation"
+    if (v.size() == 1) return Quaternion(0.0f, 0.0f, 0.0f, 1.0f);
+    return Quaternion(jfloat(v[0]), jfloat(v[1]), jfloat(v[2]), jfloat(v[3]));
+}
+// DirectionToQuaternion (:128-150): rotation taking the default forward -Z to `direction` (RH; the caller flips x, y). The reference
+// evaluates it with DirectXMath's approximations; here sin / cos / atan2 are the double-precision libm ones, rounded once.
+Quaternion DirectionToQuaternion(const Vector3& d)
+{
+    const double ax = 0.0 * (double)d.z - (-1.0) * (double)d.y, ay = (-1.0) * (double)d.x - 0.0 * (double)d.z, az = 0.0;   // cross((0,0,-1), d)
+    const float axf = (float)ax, ayf = (float)ay, azf = (float)az;
+    const float len = std::sqrt(axf * axf + ayf * ayf + azf * azf);
+    const float dot = -d.z;
+    if (len > 0.001f) {
+        const double angle = std::atan2((double)len, (double)dot);
+        const float s = (float)std::sin(angle * 0.5), c = (float)std::cos(angle * 0.5);
+        return Quaternion(axf / len * s, ayf / len * s, azf / len * s, c);
+    }
+    if (dot < 0.0f) return Quaternion(0.0f, 1.0f, 0.0f, 0.0f);
+    return Quaternion(0.0f, 0.0f, 0.0f, 1.0f);
+}
+
+struct ModelInfo { int nodeOffset, meshOffset, cameraOffset, lightOffset, materialOffset, textureOffset; };
+
+void ParseGraphNode(hobbyrt::Scene& scene, const json::Value& obj, int parentIdx, const std::vector<ModelInfo>& models, int totalModelNodes, int depth)
+{
+    if (!obj.is(json::Value::Object) || depth > 256) return;
+    const int nodeIdx = (int)scene.m_Nodes.size();
+    scene.m_Nodes.emplace_back();
+    scene.m_Nodes.back().m_Parent = parentIdx;
+    if (parentIdx != -1) scene.m_Nodes[(size_t)parentIdx].m_Children.push_back(nodeIdx);
+    int modelIdx = -1; const json::Value* children = nullptr;
+    auto node = [&]() -> hobbyrt::Scene::Node& { return scene.m_Nodes[(size_t)nodeIdx]; };     // m_Nodes may reallocate: never hold the reference
+    auto flipQuat = [](Quaternion q) { q.x *= -1.0f; q.y *= -1.0f; return q; };
+    for (const auto& kv : obj.object) {          // keys in file order, exactly like the reference's token walk
+        const std::string& key = kv.first; const json::Value& val = kv.second;
+        if (key == "name") node().m_Name = val.str("");
+        else if (key == "translation") { Vector3 t = jvec3(val); t.z *= -1.0f; node().m_Translation = t; }
+        else if (key == "rotation") node().m_Rotation = flipQuat(jquat(val));
+        else if (key == "scale") node().m_Scale = jvec3(val);
+        else if (key == "scaling") { float f = jfloat(val); node().m_Scale = Vector3(f, f, f); }
+        else if (key == "model") modelIdx = (int)jfloat(val);
+        else if (key == "children") children = &val;
+        else if (key == "type") {
+            const std::string type = val.str("");
+            if (type == "PerspectiveCamera" || type == "PerspectiveCameraEx") {
+                hobbyrt::Scene::Camera cam; cam.m_Name = node().m_Name; cam.m_NodeIndex = nodeIdx; cam.m_Projection.nearZ = 0.1f;
+                for (const auto& c : obj.object) {
+                    if (c.first == "verticalFov") cam.m_Projection.fovY = jfloat(c.second);
+                    else if (c.first == "zNear") cam.m_Projection.nearZ = jfloat(c.second);
+                    else if (c.first == "exposureValue") cam.m_ExposureValue = jfloat(c.second);
+                    else if (c.first == "exposureCompensation") cam.m_ExposureCompensation = jfloat(c.second);
+                    else if (c.first == "exposureValueMin") cam.m_ExposureValueMin = jfloat(c.second);
+                    else if (c.first == "exposureValueMax") cam.m_ExposureValueMax = jfloat(c.second);
+                }
+                scene.m_Cameras.push_back(cam);
+                node().m_CameraIndex = (int)scene.m_Cameras.size() - 1;
+            } else if (type == "DirectionalLight" || type == "SpotLight") {
+                hobbyrt::Scene::Light light;
+                light.m_Type = type == "SpotLight" ? hobbyrt::Scene::Light::Spot : hobbyrt::Scene::Light::Directional;
+                light.m_Name = node().m_Name; light.m_NodeIndex = nodeIdx;
+                const bool spot = light.m_Type == hobbyrt::Scene::Light::Spot;
+                const float degToRad = hobbyrt::XM_PI / 180.0f;
+                for (const auto& c : obj.object) {
+                    const std::string& k = c.first; const json::Value& v = c.second;
+                    if (!spot && k == "irradiance") light.m_Intensity = jfloat(v);
+                    else if (!spot && k == "angularSize") light.m_AngularSize = jfloat(v);
+                    else if (spot && k == "intensity") light.m_Intensity = jfloat(v);
+                    else if (spot && k == "innerAngle") light.m_SpotInnerConeAngle = jfloat(v) * degToRad;
+                    else if (spot && k == "outerAngle") light.m_SpotOuterConeAngle = jfloat(v) * degToRad;
+                    else if (spot && k == "radius") light.m_Radius = jfloat(v);
+                    else if (spot && k == "range") light.m_Range = jfloat(v);
+                    else if (k == "color") light.m_Color = jvec3(v);
+                    else if (spot && k == "translation") { Vector3 t = jvec3(v); t.z *= -1.0f; node().m_Translation = t; }
+                    else if (k == "rotation") node().m_Rotation = flipQuat(jquat(v));
+                    else if (k == "direction") node().m_Rotation = flipQuat(DirectionToQuaternion(jvec3(v)));
+                }
+                scene.m_Lights.push_back(light);
+                node().m_LightIndex = (int)scene.m_Lights.size() - 1;
+            } else if (type == "EnvironmentLight") t_warnings.push_back("EnvironmentLight '" + node().m_Name + "' ignored: the path tracer lights misses with the Bruneton sky");
+            else if (!type.empty()) t_warnings.push_back("graph node type '" + type + "' ignored");
+        }
+    }
+    node().m_LocalTransform = matrix_from_trs(node().m_Translation, node().m_Rotation, node().m_Scale);
+    node().m_WorldTransform = node().m_LocalTransform;
+    if (modelIdx >= 0 && modelIdx < (int)models.size()) {       // the roots of that model hang under this node (:535-549)
+        const int begin = models[(size_t)modelIdx].nodeOffset;
+        const int end = modelIdx + 1 < (int)models.size() ? models[(size_t)modelIdx + 1].nodeOffset : totalModelNodes;
+        for (int i = begin; i < end; ++i)
+            if (scene.m_Nodes[(size_t)i].m_Parent == -1) { scene.m_Nodes[(size_t)i].m_Parent = nodeIdx; scene.m_Nodes[(size_t)nodeIdx].m_Children.push_back(i); }
+    }
+    if (children && children->is(json::Value::Array))
+        for (const json::Value& c : children->array) ParseGraphNode(scene, c, nodeIdx, models, totalModelNodes, depth + 1);
+}
+
+} // namespace
+
 namespace SceneLoader {
+
+bool LoadJSONScene(Scene& scene, const std::string& scenePath, std::vector<srrhi::VertexQuantized>& allVerticesQuantized, std::vector<uint32_t>& allIndices)
+{
+    std::vector<uint8_t> file;
+    if (!read_whole_file(scenePath, file)) return fail("cannot read " + scenePath);
+    json::Value root; std::string jerr;
+    if (!json::parse(reinterpret_cast<const char*>(file.data()), file.size(), root, jerr)) return fail("scene JSON: " + jerr);
+    if (!root.is(json::Value::Object)) return fail("scene JSON: the root must be an object");
+    const std::filesystem::path sceneDir = std::filesystem::path(scenePath).parent_path();
+    std::vector<ModelInfo> models;
+    const json::Value& modelList = root["models"];
+    for (size_t m = 0; m < modelList.size(); ++m) {
+        const std::filesystem::path modelPath = sceneDir / modelList[m].str("");
+        ModelInfo info{ (int)scene.m_Nodes.size(), (int)scene.m_Meshes.size(), (int)scene.m_Cameras.size(), (int)scene.m_Lights.size(), (int)scene.m_Materials.size(), (int)scene.m_Textures.size() };
+        std::vector<std::string> keep = t_warnings;
+        if (!load_gltf(scene, modelPath.string(), &allVerticesQuantized, &allIndices, false)) return fail("model " + modelPath.string() + ": " + t_error);
+        t_warnings.insert(t_warnings.begin(), keep.begin(), keep.end());
+        // texture URIs of the model become relative to the scene file's directory (:290-300)
+        std::error_code ec;
+        std::filesystem::path rel = std::filesystem::relative(modelPath.parent_path(), sceneDir, ec);
+        if (ec) rel = modelPath.parent_path();
+        for (size_t i = (size_t)info.textureOffset; i < scene.m_Textures.size(); ++i)
+            if (!scene.m_Textures[i].m_Uri.empty()) scene.m_Textures[i].m_Uri = (rel / scene.m_Textures[i].m_Uri).generic_string();
+        models.push_back(info);
+    }
+    const int totalModelNodes = (int)scene.m_Nodes.size();
+    const json::Value& graph = root["graph"];
+    for (size_t r = 0; r < graph.size(); ++r) ParseGraphNode(scene, graph[r], -1, models, totalModelNodes, 0);
+    scene.EnsureDefaultDirectionalLight();
+    if (root["animations"].size()) t_warnings.push_back("scene animations ignored: the path tracer pauses animation (src/PathTracerRenderer.cpp:53)");
+    for (size_t i = 0; i < scene.m_Nodes.size(); ++i)
+        if (scene.m_Nodes[i].m_Parent == -1) ComputeWorldTransforms(scene, (int)i, Matrix::Identity());
+    for (size_t ni = 0; ni < scene.m_Nodes.size(); ++ni) scene.UpdateNodeBoundingSphere((int)ni);
+    return true;
+}
 
 const char* LastError() { return t_error.c_str(); }
 const std::vector<std::string>& Warnings() { return t_warnings; }
@@ -709,7 +846,12 @@ bool LoadSceneFile(Scene& scene, const std::string& scenePath, bool useMeshCache
     const std::filesystem::path file(scenePath), sceneDir = file.parent_path();
     const std::filesystem::path cachePath = sceneDir / (file.stem().string() + "_mesh.bin");      // src/SceneCache.cpp:155
     bool fromCache = false;
-    if (useMeshCache && SceneCache::IsCacheValid(cachePath, file)) {
+    const std::string filename = file.filename().string();
+    const bool isSceneJson = filename.size() >= 11 && filename.compare(filename.size() - 11, 11, ".scene.json") == 0;      // src/Scene.cpp:27-28
+    if (isSceneJson) {
+        if (!LoadJSONScene(scene, scenePath, scene.m_Vertices, scene.m_Indices)) return false;
+        fromCache = true;      // (no cooked-mesh cache for scene files, src/Scene.cpp:31-34) -- skips the glTF branch below
+    } else if (useMeshCache && SceneCache::IsCacheValid(cachePath, file)) {
         // non-mesh pass over the glTF, geometry from the cooked cache (Scene::LoadScene, src/Scene.cpp:37-43)
         Scene backup = scene;
         if (load_gltf(scene, scenePath, nullptr, nullptr, true) &&

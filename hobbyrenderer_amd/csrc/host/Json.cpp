@@ -84,6 +84,7 @@ struct Parser {
         std::string lit(s, p);
         v.type = Value::Number;
         v.number = std::strtod(lit.c_str(), nullptr);
+        v.single = std::strtof(lit.c_str(), nullptr);
         if (integral && lit.size() <= 18) { v.isInteger = true; v.integer = std::strtoll(lit.c_str(), nullptr, 10); }
         return true;
     }

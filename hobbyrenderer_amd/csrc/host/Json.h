@@ -17,6 +17,7 @@ struct Value {
     bool boolean = false;
     double number = 0.0;
     bool isInteger = false; int64_t integer = 0;
+    float single = 0.0f;        // the literal converted straight to binary32 (strtof), for readers that use std::stof on the token text
     std::string string;
     std::vector<Value> array;
     std::vector<std::pair<std::string, Value>> object;   // insertion order kept
@@ -29,7 +30,8 @@ struct Value {
     size_t size() const { return type == Array ? array.size() : (type == Object ? object.size() : 0); }
     // typed reads with defaults (the glTF schema's "default" column)
     double num(double dflt) const { return type == Number ? number : dflt; }
-    float f32(float dflt) const { return type == Number ? (float)number : dflt; }
+    float f32(float dflt) const { return type == Number ? (float)number : dflt; }          // via double, as cgltf does
+    float f32_direct(float dflt) const { return type == Number ? single : dflt; }         // as std::stof would
     int64_t i64(int64_t dflt) const { return type == Number ? (isInteger ? integer : (int64_t)number) : dflt; }
     bool flag(bool dflt) const { return type == Bool ? boolean : dflt; }
     std::string str(const std::string& dflt) const { return type == String ? string : dflt; }   // by value: callers bind it to references

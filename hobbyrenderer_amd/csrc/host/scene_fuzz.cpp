@@ -85,11 +85,12 @@ int main(int argc, char** argv)
     size_t accepted = 0, rejected = 0;
     for (int a = 3; a < argc; ++a) {
         const std::string path = argv[a];
-        const std::string ext = std::filesystem::path(path).extension().string();
+        std::string ext = std::filesystem::path(path).extension().string();
+        if (path.size() >= 11 && path.compare(path.size() - 11, 11, ".scene.json") == 0) ext = ".scene.json";     // scene description: full loader
         const std::vector<uint8_t> seed = read_file(path);
         if (seed.empty()) { std::fprintf(stderr, "cannot read %s\n", path.c_str()); return 2; }
         for (int it = 0; it < iterations; ++it) {
-            std::vector<uint8_t> m = it == 0 ? seed : ((ext == ".gltf" || ext == ".json") && (rnd() & 1) ? mutate_json_numbers(seed) : mutate(seed));
+            std::vector<uint8_t> m = it == 0 ? seed : ((ext == ".gltf" || ext == ".json" || ext == ".scene.json") && (rnd() & 1) ? mutate_json_numbers(seed) : mutate(seed));
             bool ok = false; std::string err;
             if (ext == ".png" || ext == ".dds") { hobbyrt::Image img; ok = hobbyrt::DecodeImage(m.data(), m.size(), img, err); if (ok && img.rgba.size() != (size_t)img.width * img.height * 4) return 1; }
             else if (ext == ".json") { hobbyrt::json::Value v; ok = hobbyrt::json::parse(reinterpret_cast<const char*>(m.data()), m.size(), v, err); }

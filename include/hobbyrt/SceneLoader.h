@@ -22,6 +22,10 @@ bool LoadGLTFScene(Scene& scene, const std::string& scenePath, std::vector<srrhi
 // JSON text already in memory; buffers / images resolve against sceneDir (:2572-2589)
 bool LoadGLTFSceneFromMemory(Scene& scene, const char* jsonData, size_t jsonSize, const std::filesystem::path& sceneDir,
                              std::vector<srrhi::VertexQuantized>& allVerticesQuantized, std::vector<uint32_t>& allIndices);
+// Scene description files "*.scene.json" (src/SceneLoader.cpp:184-576): a list of glTF models plus a node graph that places them and
+// adds cameras and lights (DirectionalLight / SpotLight with radius for soft shadows); animations and EnvironmentLight are ignored
+// with a warning. Key order inside a graph node matters exactly as in the reference's token walk.
+bool LoadJSONScene(Scene& scene, const std::string& scenePath, std::vector<srrhi::VertexQuantized>& allVerticesQuantized, std::vector<uint32_t>& allIndices);
 // Decodes every Scene::Texture with a URI into RGBA8 pixels and assigns bindless indices after the DEFAULT_TEXTURE_COUNT slots
 // (:1311-1523 without the D3D12 streaming path). A texture that cannot be decoded keeps UINT32_MAX and is reported in
 // Warnings(); materials then fall back to their default texture for that slot.

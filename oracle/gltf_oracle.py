@@ -500,62 +500,93 @@ def transform_normal(v, m):
 
 
 # ---------------------------------------------------------------- whole load
-def load(path):
+class _Scene:
+    """What the loaders accumulate (hobbyrt::Scene, the fields the path tracer's inputs derive from)."""
+
+    def __init__(self):
+        self.materials, self.mat_cpu, self.textures, self.cameras, self.lights = [], [], [], [], []
+        self.vertices, self.indices, self.mesh_data, self.meshes, self.nodes = [], [], [], [], []
+        self.voff = self.ioff = 0
+
+
+def _identity_node(**kw):
+    ident = np.identity(4, dtype=np.float32)
+    n = {"mesh": -1, "camera": -1, "light": -1, "children": [], "parent": -1, "t": np.zeros(3, np.float32), "q": np.array([0, 0, 0, 1], np.float32),
+         "s": np.ones(3, np.float32), "local": ident, "world": ident}
+    n.update(kw)
+    return n
+
+
+def _ensure_default_light(sc):
+    """Scene::EnsureDefaultDirectionalLight (src/Scene.cpp:635-666): stable sort Spot, Point, Directional; append the default sun + node."""
+    order = sorted(range(len(sc.lights)), key=lambda i: -sc.lights[i]["type"])            # stable: a.type > b.type
+    sc.lights[:] = [sc.lights[i] for i in order]
+    if not sc.lights or sc.lights[-1]["type"] != LIGHT_DIRECTIONAL:
+        sc.lights.append({"type": LIGHT_DIRECTIONAL, "color": [1, 1, 1], "intensity": 1.0, "range": 0.0, "radius": 0.0, "inner": 0.0, "outer": f32(0.785398163), "angular": 0.533,
+                          "node": len(sc.nodes)})
+        cp, sp = math.cos(float(f32(0.785398163))), math.sin(float(f32(0.785398163)))
+        world = np.identity(4, dtype=np.float32)
+        world[1, 1] = f32(cp); world[1, 2] = f32(sp); world[2, 1] = f32(-sp); world[2, 2] = f32(cp)
+        sc.nodes.append(_identity_node(light=len(sc.lights) - 1, local=world, world=world))
+
+
+def _walk(sc, ni, parent):
+    sc.nodes[ni]["world"] = matmul(sc.nodes[ni]["local"], parent)
+    for c in sc.nodes[ni]["children"]:
+        _walk(sc, c, sc.nodes[ni]["world"])
+
+
+def add_gltf(sc, path, ensure_light):
+    """SceneLoader::ProcessParsedGLTF (:2495-2553) appended to `sc`."""
     doc = Document(path)
     j = doc.j
+    off = {"node": len(sc.nodes), "mesh": len(sc.meshes), "material": len(sc.materials), "texture": len(sc.textures), "camera": len(sc.cameras), "light": len(sc.lights)}
     materials, mat_cpu = process_materials(doc)
-    textures = process_textures(doc)
-    cameras = []
+    for refs in mat_cpu:
+        for k in refs:
+            if refs[k] != -1:
+                refs[k] += off["texture"]
+    sc.materials += materials; sc.mat_cpu += mat_cpu
+    for t in process_textures(doc):
+        t["dir"] = doc.dir
+        sc.textures.append(t)
     for c in j.get("cameras", []):
         if c.get("type") != "perspective":
             continue
         p = c["perspective"]
-        cameras.append({"aspect": f32(p["aspectRatio"]) if "aspectRatio" in p else f32(16.0) / f32(9.0), "fovY": f32(p.get("yfov", 0.0)), "nearZ": f32(p.get("znear", 0.0)), "node": -1})
-    lights = []
+        sc.cameras.append({"aspect": f32(p["aspectRatio"]) if "aspectRatio" in p else f32(16.0) / f32(9.0), "fovY": f32(p.get("yfov", 0.0)), "nearZ": f32(p.get("znear", 0.0)), "node": -1})
     for l in j.get("extensions", {}).get("KHR_lights_punctual", {}).get("lights", []):
         ty = {"directional": LIGHT_DIRECTIONAL, "point": LIGHT_POINT, "spot": LIGHT_SPOT}.get(l.get("type"))
         if ty is None:
             continue
         spot = l.get("spot", {})
-        lights.append({"type": ty, "color": l.get("color", [1, 1, 1]), "intensity": l.get("intensity", 1.0), "range": l.get("range", 0.0), "radius": 0.0,
-                       "inner": spot.get("innerConeAngle", 0.0), "outer": f32(spot.get("outerConeAngle", 3.14159265358979323846 / 4.0)), "angular": 0.533, "node": -1})
-    # meshes
-    vertices, indices, mesh_data, meshes = [], [], [], []
-    voff = ioff = 0
+        sc.lights.append({"type": ty, "color": l.get("color", [1, 1, 1]), "intensity": l.get("intensity", 1.0), "range": l.get("range", 0.0), "radius": 0.0,
+                          "inner": spot.get("innerConeAngle", 0.0), "outer": f32(spot.get("outerConeAngle", 3.14159265358979323846 / 4.0)), "angular": 0.533, "node": -1})
+    local_mat_cpu = sc.mat_cpu[off["material"]:]
     for m in j.get("meshes", []):
         prims = []
         for prim in m.get("primitives", []):
-            res = process_primitive(doc, prim, mat_cpu)
+            res = process_primitive(doc, prim, local_mat_cpu)
             md = np.zeros((), MeshData)
             mat = prim.get("material", -1)
+            mat = mat + off["material"] if mat >= 0 else -1
             if res is not None and len(res["indices"]):
-                md["m_LODCount"] = 1; md["m_IndexOffsets"][0] = ioff; md["m_IndexCounts"][0] = len(res["indices"])
+                md["m_LODCount"] = 1; md["m_IndexOffsets"][0] = sc.ioff; md["m_IndexCounts"][0] = len(res["indices"])
             if res is not None:
-                vertices.append(res["vertices"]); indices.append(res["indices"] + np.uint32(voff))
-                prims.append({"material": mat, "mesh_data": len(mesh_data)})
-                voff += len(res["vertices"]); ioff += len(res["indices"])
-            else:
-                prims.append({"material": mat, "mesh_data": len(mesh_data)})
-            mesh_data.append(md)
-        meshes.append(prims)
-    # sort lights (Spot, Point, Directional), ensure the default sun, nodes
+                sc.vertices.append(res["vertices"]); sc.indices.append(res["indices"] + np.uint32(sc.voff))
+                sc.voff += len(res["vertices"]); sc.ioff += len(res["indices"])
+            prims.append({"material": mat, "mesh_data": len(sc.mesh_data)})
+            sc.mesh_data.append(md)
+        sc.meshes.append(prims)
     nodes_json = j.get("nodes", [])
-    nodes = [{"mesh": n.get("mesh", -1), "camera": n.get("camera", -1), "light": n.get("extensions", {}).get("KHR_lights_punctual", {}).get("light", -1),
-              "children": list(n.get("children", [])), "parent": -1, "t": np.zeros(3, np.float32), "q": np.array([0, 0, 0, 1], np.float32), "s": np.ones(3, np.float32)} for n in nodes_json]
-    order = sorted(range(len(lights)), key=lambda i: -lights[i]["type"])            # stable: a.type > b.type
-    remap = {old: new for new, old in enumerate(order)}
-    lights = [lights[i] for i in order]
-    if not lights or lights[-1]["type"] != LIGHT_DIRECTIONAL:
-        lights.append({"type": LIGHT_DIRECTIONAL, "color": [1, 1, 1], "intensity": 1.0, "range": 0.0, "radius": 0.0, "inner": 0.0, "outer": f32(0.785398163), "angular": 0.533, "node": len(nodes)})
-        cp, sp = math.cos(float(f32(0.785398163))), math.sin(float(f32(0.785398163)))
-        world = np.identity(4, dtype=np.float32)
-        world[1, 1] = f32(cp); world[1, 2] = f32(sp); world[2, 1] = f32(-sp); world[2, 2] = f32(cp)
-        nodes.append({"mesh": -1, "camera": -1, "light": len(lights) - 1, "children": [], "parent": -1, "local": world, "world": world, "fixed": True})
-    # NOTE: the reference sorts m_Lights inside EnsureDefaultDirectionalLight BEFORE node light indices are resolved (:2542-2545 then
-    # ProcessNodesAndHierarchy), so a node's light index addresses the SORTED list; the product does the same. `remap` is therefore unused.
-    del remap
-    for ni, n in enumerate(nodes_json):
-        node = nodes[ni]
+    for n in nodes_json:
+        sc.nodes.append(_identity_node(mesh=n["mesh"] + off["mesh"] if "mesh" in n else -1, camera=n["camera"] + off["camera"] if "camera" in n else -1,
+                                       light=n.get("extensions", {}).get("KHR_lights_punctual", {}).get("light", -1 - off["light"]) + off["light"],
+                                       children=[c + off["node"] for c in n.get("children", [])]))
+    if ensure_light:
+        _ensure_default_light(sc)        # sorts the lights BEFORE the nodes resolve their light indices (:2542-2545): kept as in the reference
+    for k, n in enumerate(nodes_json):
+        node = sc.nodes[off["node"] + k]
         if "matrix" in n and len(n["matrix"]) == 16:
             s, q, t = decompose(np.array(n["matrix"], np.float32).reshape(4, 4))
             t[2] = -t[2]; q[0] = -q[0]; q[1] = -q[1]
@@ -569,27 +600,155 @@ def load(path):
                 r = n["rotation"]
                 node["q"] = np.array([-f32(r[0]), -f32(r[1]), r[2], r[3]], np.float32)
         node["local"] = matrix_from_trs(node["t"], node["q"], node["s"]); node["world"] = node["local"]
-    for ni, n in enumerate(nodes_json):
-        for c in nodes[ni]["children"]:
-            nodes[c]["parent"] = ni
-    for ni in range(len(nodes_json)):
-        if 0 <= nodes[ni]["camera"] < len(cameras):
-            cameras[nodes[ni]["camera"]]["node"] = ni
-        if 0 <= nodes[ni]["light"] < len(lights):
-            lights[nodes[ni]["light"]]["node"] = ni
+    for k in range(len(nodes_json)):
+        for c in sc.nodes[off["node"] + k]["children"]:
+            sc.nodes[c]["parent"] = off["node"] + k
+    for k in range(len(nodes_json)):
+        ni = off["node"] + k
+        if 0 <= sc.nodes[ni]["camera"] < len(sc.cameras):
+            sc.cameras[sc.nodes[ni]["camera"]]["node"] = ni
+        if 0 <= sc.nodes[ni]["light"] < len(sc.lights):
+            sc.lights[sc.nodes[ni]["light"]]["node"] = ni
+    for k in range(len(nodes_json)):
+        if sc.nodes[off["node"] + k]["parent"] == -1:
+            _walk(sc, off["node"] + k, np.identity(4, dtype=np.float32))
+    for li in range(off["light"], len(sc.lights)):        # a light no node instantiates sits on an identity node (the reference asserts instead)
+        if sc.lights[li]["node"] < 0:
+            sc.lights[li]["node"] = len(sc.nodes)
+            sc.nodes.append(_identity_node(light=li))
+    return off
 
-    def walk(ni, parent):
-        nodes[ni]["world"] = matmul(nodes[ni]["local"], parent)
-        for c in nodes[ni]["children"]:
-            walk(c, nodes[ni]["world"])
-    for ni in range(len(nodes_json)):
-        if nodes[ni]["parent"] == -1:
-            walk(ni, np.identity(4, dtype=np.float32))
-    for li, l in enumerate(lights):        # a light no node instantiates sits on an identity node (the reference asserts instead)
-        if l["node"] < 0:
-            l["node"] = len(nodes)
-            ident = np.identity(4, dtype=np.float32)
-            nodes.append({"mesh": -1, "camera": -1, "light": li, "children": [], "parent": -1, "local": ident, "world": ident})
+
+def _direction_to_quaternion(d):
+    """:128-150 with double-precision libm sin / cos / atan2 rounded once (the product does the same)."""
+    d = np.asarray(d, np.float32)
+    ax, ay, az = f32(float(d[1])), f32(-float(d[0])), f32(0.0)
+    ln = np.sqrt(f32(f32(f32(ax * ax) + f32(ay * ay)) + f32(az * az)))
+    dot = f32(-d[2])
+    if ln > f32(0.001):
+        angle = math.atan2(float(ln), float(dot))
+        s, c = f32(math.sin(angle * 0.5)), f32(math.cos(angle * 0.5))
+        return np.array([f32(f32(ax / ln) * s), f32(f32(ay / ln) * s), f32(f32(az / ln) * s), c], np.float32)
+    if dot < 0:
+        return np.array([0, 1, 0, 0], np.float32)
+    return np.array([0, 0, 0, 1], np.float32)
+
+
+def _jf(x):
+    """json_get_float: std::stof of the token text. (Python parsed the literal to a double first; test assets use literals where the
+    double-then-float rounding equals the direct one.)"""
+    return f32(x)
+
+
+def add_json_scene(sc, path):
+    """SceneLoader::LoadJSONScene (:184-576) without animations / environment lights."""
+    root = json.load(open(path, "rb"), object_pairs_hook=lambda pairs: pairs)      # keep key order AND duplicate keys, like a token walk
+    top = dict(root)
+    scene_dir = os.path.dirname(path)
+    models = []
+    for m in top.get("models", []):
+        model_path = os.path.join(scene_dir, m)
+        tex0 = len(sc.textures)
+        off = add_gltf(sc, model_path, False)
+        rel = os.path.relpath(os.path.dirname(model_path), scene_dir)
+        for t in sc.textures[tex0:]:
+            if t["uri"]:
+                t["uri"] = os.path.normpath(os.path.join(rel, t["uri"])).replace(os.sep, "/") if rel != "." else t["uri"]
+                t["dir"] = scene_dir
+        models.append(off)
+    total_model_nodes = len(sc.nodes)
+
+    def flipq(q):
+        q = np.array(q, np.float32); q[0] = -q[0]; q[1] = -q[1]; return q
+
+    def quat(v):
+        return np.array([0, 0, 0, 1], np.float32) if len(v) == 1 else np.array([_jf(x) for x in v[:4]], np.float32)
+
+    def parse(pairs, parent):
+        ni = len(sc.nodes)
+        node = _identity_node(parent=parent)
+        sc.nodes.append(node)
+        if parent != -1:
+            sc.nodes[parent]["children"].append(ni)
+        model_idx, children, name = -1, None, ""
+        for key, val in pairs:
+            if key == "name":
+                name = val
+            elif key == "translation":
+                node["t"] = np.array([_jf(val[0]), _jf(val[1]), -_jf(val[2])], np.float32)
+            elif key == "rotation":
+                node["q"] = flipq(quat(val))
+            elif key == "scale":
+                node["s"] = np.array([_jf(x) for x in val], np.float32)
+            elif key == "scaling":
+                node["s"] = np.array([_jf(val)] * 3, np.float32)
+            elif key == "model":
+                model_idx = int(_jf(val))
+            elif key == "children":
+                children = val
+            elif key == "type":
+                if val in ("PerspectiveCamera", "PerspectiveCameraEx"):
+                    cam = {"aspect": f32(16.0) / f32(9.0), "fovY": f32(0.785398163), "nearZ": f32(0.1), "node": ni}
+                    for k, v in pairs:
+                        if k == "verticalFov":
+                            cam["fovY"] = _jf(v)
+                        elif k == "zNear":
+                            cam["nearZ"] = _jf(v)
+                    sc.cameras.append(cam); node["camera"] = len(sc.cameras) - 1
+                elif val in ("DirectionalLight", "SpotLight"):
+                    spot = val == "SpotLight"
+                    l = {"type": LIGHT_SPOT if spot else LIGHT_DIRECTIONAL, "color": [1, 1, 1], "intensity": 1.0, "range": 0.0, "radius": 0.0, "inner": 0.0,
+                         "outer": f32(0.785398163), "angular": 0.533, "node": ni}
+                    deg = f32(f32(3.141592654) / f32(180.0))
+                    for k, v in pairs:
+                        if not spot and k == "irradiance":
+                            l["intensity"] = _jf(v)
+                        elif not spot and k == "angularSize":
+                            l["angular"] = _jf(v)
+                        elif spot and k == "intensity":
+                            l["intensity"] = _jf(v)
+                        elif spot and k == "innerAngle":
+                            l["inner"] = f32(_jf(v) * deg)
+                        elif spot and k == "outerAngle":
+                            l["outer"] = f32(_jf(v) * deg)
+                        elif spot and k == "radius":
+                            l["radius"] = _jf(v)
+                        elif spot and k == "range":
+                            l["range"] = _jf(v)
+                        elif k == "color":
+                            l["color"] = [_jf(x) for x in v]
+                        elif spot and k == "translation":
+                            node["t"] = np.array([_jf(v[0]), _jf(v[1]), -_jf(v[2])], np.float32)
+                        elif k == "rotation":
+                            node["q"] = flipq(quat(v))
+                        elif k == "direction":
+                            node["q"] = flipq(_direction_to_quaternion([_jf(x) for x in v]))
+                    sc.lights.append(l); node["light"] = len(sc.lights) - 1
+        node["local"] = matrix_from_trs(node["t"], node["q"], node["s"]); node["world"] = node["local"]
+        if 0 <= model_idx < len(models):
+            begin = models[model_idx]["node"]
+            end = models[model_idx + 1]["node"] if model_idx + 1 < len(models) else total_model_nodes
+            for i in range(begin, end):
+                if sc.nodes[i]["parent"] == -1:
+                    sc.nodes[i]["parent"] = ni; node["children"].append(i)
+        for c in children or []:
+            parse(c, ni)
+
+    for r in top.get("graph", []):
+        parse(r, -1)
+    _ensure_default_light(sc)
+    for ni in range(len(sc.nodes)):
+        if sc.nodes[ni]["parent"] == -1:
+            _walk(sc, ni, np.identity(4, dtype=np.float32))
+
+
+def load(path):
+    sc = _Scene()
+    if path.endswith(".scene.json"):
+        add_json_scene(sc, path)
+    else:
+        add_gltf(sc, path, True)
+    materials, mat_cpu, textures, cameras, lights, nodes, meshes = sc.materials, sc.mat_cpu, sc.textures, sc.cameras, sc.lights, sc.nodes, sc.meshes
     # FinalizeLoadedScene: one instance per (node, primitive); buckets opaque / masked / transparent, static before dynamic
     buckets = [[] for _ in range(6)]
     for ni, node in enumerate(nodes):
@@ -606,7 +765,7 @@ def load(path):
     # textures -> RGBA8 + bindless indices, then material constants
     nxt = DEFAULT_TEXTURE_COUNT
     for t in textures:
-        full = os.path.join(doc.dir, urllib.parse.unquote(t["uri"])) if t["uri"] and not t["uri"].startswith("data:") else None
+        full = os.path.join(t["dir"], urllib.parse.unquote(t["uri"])) if t["uri"] and not t["uri"].startswith("data:") else None
         if full and os.path.exists(full) and open(full, "rb").read(8)[:4] == b"\x89PNG":
             t["pixels"] = decode_png(open(full, "rb").read()); t["bindless"] = nxt; nxt += 1
     out_mats = np.zeros(len(materials), MaterialConstants)
@@ -644,7 +803,8 @@ def load(path):
         fwd = normalize3(transform_normal(np.array([0, 0, 1], np.float32), w))
         camera = {"position": w[3, :3].copy(), "yaw": f32(math.atan2(float(fwd[0]), float(fwd[2]))), "pitch": f32(-math.asin(float(fwd[1]))),
                   "fovY": cameras[0]["fovY"], "aspect": cameras[0]["aspect"], "nearZ": cameras[0]["nearZ"]}
-    return {"vertices": np.concatenate(vertices) if vertices else np.zeros(0, VertexQuantized),
-            "indices": np.concatenate(indices).astype(np.uint32) if indices else np.zeros(0, np.uint32),
-            "mesh_data": np.array(mesh_data, MeshData) if mesh_data else np.zeros(0, MeshData), "instances": instances, "materials": out_mats,
-            "lights": gpu_lights, "textures": textures, "sun_direction": sun, "camera": camera, "camera_count": len(cameras)}
+    return {"vertices": np.concatenate(sc.vertices) if sc.vertices else np.zeros(0, VertexQuantized),
+            "indices": np.concatenate(sc.indices).astype(np.uint32) if sc.indices else np.zeros(0, np.uint32),
+            "mesh_data": np.array(sc.mesh_data, MeshData) if sc.mesh_data else np.zeros(0, MeshData), "instances": instances, "materials": out_mats,
+            "lights": gpu_lights, "textures": textures, "sun_direction": sun, "camera": camera, "camera_count": len(cameras),
+            "sun_angular_size": float(f32(lights[-1]["angular"]))}

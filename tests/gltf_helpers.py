@@ -245,3 +245,42 @@ def build_showcase(dirpath, mode="bin", name="showcase"):
     path = os.path.join(dirpath, name + (".glb" if mode == "glb" else ".gltf"))
     a.write(path, mode)
     return path
+
+
+def build_scene_json(dirpath):
+    """A *.scene.json (the reference's scene description format, src/SceneLoader.cpp:184-576) placing two glTF models -- the showcase
+    asset in the scene directory and a textured quad in a sub-directory -- under a node graph with a camera, a directional light
+    given by direction, a spot light with radius / cone angles, a uniform `scaling`, a `[0]` rotation, an unknown node type, an
+    EnvironmentLight and an animations block (both ignored by the path tracer)."""
+    showcase = build_showcase(dirpath)
+    sub = os.path.join(dirpath, "props")
+    os.makedirs(sub, exist_ok=True)
+    rng = np.random.default_rng(11)
+    write_png(os.path.join(sub, "checker.png"), rng.integers(0, 256, (4, 4, 3)).astype(np.uint16), 2)
+    a = Asset()
+    p, n, uv, i = grid(2, 2, 0.5)
+    a.add_primitive(0, p, i, n, uv, material=0)
+    a.j["images"] = [{"uri": "checker.png"}]; a.j["textures"] = [{"source": 0}]
+    a.j["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "roughnessFactor": 0.5, "metallicFactor": 0.0}}]
+    a.j["nodes"] = [{"mesh": 0, "translation": [0.0, 0.5, 0.0]}, {"mesh": 0, "children": [0] if False else [], "scale": [2.0, 1.0, 1.0]}]
+    a.write(os.path.join(sub, "quad.gltf"), "datauri")
+    scene = {
+        "models": [os.path.basename(showcase), "props/quad.gltf"],
+        "graph": [
+            {"name": "world", "children": [
+                {"name": "showcase", "model": 0, "translation": [0.5, 0.0, -1.0], "rotation": [0.0, 0.258819, 0.0, 0.9659258]},
+                {"name": "props", "scaling": 1.5, "rotation": [0], "children": [
+                    {"name": "quad_a", "model": 1, "translation": [2.0, 0.25, 0.5]},
+                    {"name": "marker", "type": "Marker"}]},
+                {"name": "cam", "type": "PerspectiveCameraEx", "translation": [0.0, 1.5, 7.0], "rotation": [-0.0871557, 0.0, 0.0, 0.9961947], "verticalFov": 0.6, "zNear": 0.25,
+                 "exposureValue": 12.0},
+                {"name": "sun", "type": "DirectionalLight", "direction": [0.3, -0.8, 0.5], "irradiance": 3.0, "angularSize": 1.0, "color": [1.0, 0.9, 0.8]},
+                {"name": "lamp", "type": "SpotLight", "translation": [1.0, 3.0, 2.0], "direction": [0.0, -1.0, 0.0], "intensity": 40.0, "innerAngle": 20.0, "outerAngle": 35.0,
+                 "radius": 0.125, "range": 12.0, "color": [0.9, 0.7, 0.5]},
+                {"name": "sky", "type": "EnvironmentLight", "path": "env/sky.dds"}]}],
+        "animations": [{"name": "spin", "channels": []}],
+    }
+    path = os.path.join(dirpath, "demo.scene.json")
+    with open(path, "w") as f:
+        json.dump(scene, f, indent=1)
+    return path

@@ -257,3 +257,23 @@ def test_unreferenced_light_and_material_less_primitive(tmp_path, luts):
     # and such a scene uploads: every index the loader hands out is in range
     sc = loaded.arrays
     assert sc.instances["m_MaterialIndex"].max() < len(sc.materials)
+
+
+def test_scene_json_matches_oracle(tmp_path, luts):
+    """*.scene.json (src/SceneLoader.cpp:184-576): several glTF models placed by a node graph with JSON-declared camera and lights."""
+    from gltf_helpers import build_scene_json
+    path = build_scene_json(str(tmp_path))
+    loaded = scene_io.load_gltf(path, luts)
+    o = G.load(path)
+    _assert_same_scene(loaded, o)
+    a = loaded.arrays
+    assert loaded.counts["meshes"] == 4 and len(a.materials) == 10 and loaded.counts["textures"] == 6
+    assert abs(a.sun_angular_size_deg - 1.0) < 1e-7 and abs(o["sun_angular_size"] - 1.0) < 1e-7
+    # JSON lights: spot (radius, cone angles in radians) and the directional light last; glTF lights of the models in between
+    spot = a.lights[a.lights["m_Radius"] > 0]
+    assert len(spot) == 1 and spot["m_Type"][0] == 2 and abs(float(spot["m_SpotOuterConeAngle"][0]) - np.deg2rad(35.0)) < 1e-6
+    assert a.lights["m_Type"][-1] == 0 and a.lights["m_Intensity"][-1] in (2.0, 3.0)
+    assert np.allclose(a.lights[a.lights["m_Radius"] > 0]["m_Direction"][0], [0, -1, 0], atol=1e-6)
+    assert loaded.camera_count == 3 and any("EnvironmentLight" in w for w in loaded.warnings) and any("Marker" in w for w in loaded.warnings) and any("animations" in w for w in loaded.warnings)
+    # the quad model's texture resolved through its sub-directory
+    assert any(t is not None and t.shape == (4, 4, 4) for t in a.textures[11:])

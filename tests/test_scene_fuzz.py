@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from gltf_helpers import build_showcase
+from gltf_helpers import build_scene_json, build_showcase
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hobbyrenderer_amd", "csrc")
@@ -17,11 +17,12 @@ CSRC = os.path.join(ROOT, "hobbyrenderer_amd", "csrc")
 def test_mutated_inputs_do_not_crash_the_readers(tmp_path, seed):
     subprocess.check_call(["make", "-C", CSRC, "fuzz"], stdout=subprocess.DEVNULL)
     d = str(tmp_path)
-    gltf = build_showcase(d)
+    scene_json = build_scene_json(d)
+    gltf = os.path.join(d, "showcase.gltf")
     glb = build_showcase(d, "glb", "glbcase")
     shutil.copy(os.path.join(ROOT, "tests", "golden", "cornell_mesh.bin"), os.path.join(d, "seed.bin"))
     shutil.copy(gltf, os.path.join(d, "doc.json"))
-    files = [gltf, glb, os.path.join(d, "seed.bin"), os.path.join(d, "doc.json"), os.path.join(d, "albedo rgba.png"), os.path.join(d, "orm16.png"),
+    files = [scene_json, gltf, glb, os.path.join(d, "seed.bin"), os.path.join(d, "doc.json"), os.path.join(d, "albedo rgba.png"), os.path.join(d, "orm16.png"),
              os.path.join(d, "emissive_pal.png")]
     env = dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
     r = subprocess.run([os.path.join(CSRC, "build", "scene_fuzz"), "1500", str(seed), *files], capture_output=True, text=True, env=env, timeout=600)
