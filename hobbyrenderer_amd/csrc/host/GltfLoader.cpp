@@ -845,22 +845,22 @@ bool LoadSceneFile(Scene& scene, const std::string& scenePath, bool useMeshCache
     t_warnings.clear();
     const std::filesystem::path file(scenePath), sceneDir = file.parent_path();
     const std::filesystem::path cachePath = sceneDir / (file.stem().string() + "_mesh.bin");      // src/SceneCache.cpp:155
-    bool fromCache = false;
+    bool geometryLoaded = false;      // by the scene description or from the cooked-mesh cache
     const std::string filename = file.filename().string();
     const bool isSceneJson = filename.size() >= 11 && filename.compare(filename.size() - 11, 11, ".scene.json") == 0;      // src/Scene.cpp:27-28
     if (isSceneJson) {
         if (!LoadJSONScene(scene, scenePath, scene.m_Vertices, scene.m_Indices)) return false;
-        fromCache = true;      // (no cooked-mesh cache for scene files, src/Scene.cpp:31-34) -- skips the glTF branch below
+        geometryLoaded = true;            // scene descriptions never use the cooked-mesh cache (src/Scene.cpp:31-34)
     } else if (useMeshCache && SceneCache::IsCacheValid(cachePath, file)) {
         // non-mesh pass over the glTF, geometry from the cooked cache (Scene::LoadScene, src/Scene.cpp:37-43)
         Scene backup = scene;
         if (load_gltf(scene, scenePath, nullptr, nullptr, true) &&
             SceneCache::LoadCookedMesh(cachePath, scene.m_Meshes, scene.m_MeshData, scene.m_Meshlets, scene.m_MeshletVertices, scene.m_MeshletTriangles, scene.m_Vertices, scene.m_Indices)) {
             for (int ni = 0; ni < (int)scene.m_Nodes.size(); ++ni) scene.UpdateNodeBoundingSphere(ni);
-            fromCache = true;
+            geometryLoaded = true;
         } else { t_warnings.push_back(std::string("mesh cache not used: ") + SceneCache::LastError()); scene = std::move(backup); }
     }
-    if (!fromCache) {
+    if (!geometryLoaded) {
         if (!load_gltf(scene, scenePath, &scene.m_Vertices, &scene.m_Indices, true)) return false;
         if (useMeshCache && !SceneCache::SaveCookedMesh(cachePath, scene.m_Meshes, scene.m_MeshData, scene.m_Meshlets, scene.m_MeshletVertices, scene.m_MeshletTriangles, scene.m_Vertices, scene.m_Indices))
             t_warnings.push_back(std::string("mesh cache not written: ") + SceneCache::LastError());
