@@ -266,7 +266,7 @@ void ProcessMaterialsAndImages(const Document& doc, hobbyrt::Scene& scene, const
             if (!t.m_Uri.empty()) {         // a .dds next to the image wins (:1281-1288)
                 std::filesystem::path dds = std::filesystem::path(t.m_Uri); dds.replace_extension(".dds");
                 std::error_code ec;
-                if (std::filesystem::exists(sceneDir / dds, ec)) t.m_Uri = dds.string();
+                if (std::filesystem::exists(sceneDir / dds, ec) && dds.string() != t.m_Uri) { t.m_SourceUri = t.m_Uri; t.m_Uri = dds.string(); }
             }
         }
         const json::Value* smp = texs[i].find("sampler");
@@ -787,7 +787,10 @@ bool LoadJSONScene(Scene& scene, const std::string& scenePath, std::vector<srrhi
         std::filesystem::path rel = std::filesystem::relative(modelPath.parent_path(), sceneDir, ec);
         if (ec) rel = modelPath.parent_path();
         for (size_t i = (size_t)info.textureOffset; i < scene.m_Textures.size(); ++i)
-            if (!scene.m_Textures[i].m_Uri.empty()) scene.m_Textures[i].m_Uri = (rel / scene.m_Textures[i].m_Uri).generic_string();
+            if (!scene.m_Textures[i].m_Uri.empty()) {
+                scene.m_Textures[i].m_Uri = (rel / scene.m_Textures[i].m_Uri).generic_string();
+                if (!scene.m_Textures[i].m_SourceUri.empty()) scene.m_Textures[i].m_SourceUri = (rel / scene.m_Textures[i].m_SourceUri).generic_string();
+            }
         models.push_back(info);
     }
     const int totalModelNodes = (int)scene.m_Nodes.size();
@@ -829,7 +832,15 @@ void LoadTexturesFromImages(Scene& scene, const std::filesystem::path& sceneDir)
         if (tex.m_Uri.empty()) { t_warnings.push_back("texture " + std::to_string(i) + " has no URI (embedded images are not loaded, as in the reference)"); continue; }
         if (tex.m_Uri.rfind("data:", 0) == 0) { t_warnings.push_back("texture " + std::to_string(i) + ": data-URI images are not loaded"); continue; }
         hobbyrt::Image img; std::string err;
-        if (!hobbyrt::LoadImageFile((sceneDir / percent_decode(tex.m_Uri)).string(), img, err)) { t_warnings.push_back("texture " + std::to_string(i) + ": " + err); continue; }
+        if (!hobbyrt::LoadImageFile((sceneDir / percent_decode(tex.m_Uri)).string(), img, err)) {
+            // a .dds sibling the host cannot decode (BC6H / BC7 / float formats go to the GPU's texture units in the reference): use the image it shadowed
+            std::string err2;
+            if (tex.m_SourceUri.empty() || !hobbyrt::LoadImageFile((sceneDir / percent_decode(tex.m_SourceUri)).string(), img, err2)) {
+                t_warnings.push_back("texture " + std::to_string(i) + ": " + err + (tex.m_SourceUri.empty() ? "" : "; " + err2));
+                continue;
+            }
+            t_warnings.push_back("texture " + std::to_string(i) + ": " + err + " -- decoded " + tex.m_SourceUri + " instead");
+        }
         tex.m_Pixels = std::move(img.rgba); tex.m_Width = img.width; tex.m_Height = img.height;
         tex.m_BindlessIndex = next++;
     }

@@ -49,6 +49,7 @@ public:
     };
     struct Texture {
         std::string m_Uri; std::vector<uint8_t> m_Pixels; uint32_t m_Width = 0, m_Height = 0;   // RGBA8_UNORM, one mip
+        std::string m_SourceUri;            // the image's own URI when m_Uri was switched to a .dds sibling (fallback if that cannot be decoded)
         uint32_t m_BindlessIndex = UINT32_MAX;
         enum SamplerType { Clamp = 0, Wrap = 1 };
         SamplerType m_Sampler = Wrap;

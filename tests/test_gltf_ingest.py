@@ -154,6 +154,11 @@ def test_dds_sibling_replaces_png(tmp_path, luts):
     open(tmp_path / "normal.dds", "wb").write(hdr + struct.pack("<IIIII", 28, 3, 0, 1, 0) + px.tobytes())
     loaded = scene_io.load_gltf(path, luts)
     assert np.array_equal(loaded.arrays.textures[12], px)          # texture 1 ("normal.png") came from normal.dds (src/SceneLoader.cpp:1281-1288)
+    # a BC7 sibling cannot be decoded on the host: the PNG it shadowed is used, with a warning
+    open(tmp_path / "orm16.dds", "wb").write(hdr + struct.pack("<IIIII", 98, 3, 0, 1, 0) + bytes(16))
+    loaded = scene_io.load_gltf(path, luts)
+    assert np.array_equal(loaded.arrays.textures[13], G.decode_png(open(tmp_path / "orm16.png", "rb").read()))
+    assert any("orm16.dds" in w and "instead" in w for w in loaded.warnings)
 
 
 def test_error_behaviour(tmp_path, luts):
