@@ -1,5 +1,6 @@
 #include "ImageDecode.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -309,11 +310,288 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
     return true;
 }
 
+
+// ------------------------------------------------------------------ JPEG (baseline / extended sequential Huffman, 8 bit)
+// Integer pipeline as in stb_image (public domain, not in the reference tree; the reference decodes through it): 12-bit fixed-point
+// inverse DCT of the jidctint family, triangle-filter chroma upsampling for 2x1 / 1x2 / 2x2, 20-bit fixed-point YCbCr -> RGB.
+// Progressive and arithmetic-coded files, 12-bit samples and CMYK are reported as unsupported.
+namespace {
+const uint8_t kDezigzag[64 + 15] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+                                     29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };
+struct JHuff { uint8_t size[257]; uint16_t code[257]; uint8_t value[256]; int maxcode[18]; int delta[17]; int count = 0; bool ok = false; };
+bool jhuff_build(JHuff& h, const uint8_t* counts, const uint8_t* vals, int nvals)
+{
+    int k = 0;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < counts[i]; ++j) { if (k >= 256) return false; h.size[k++] = (uint8_t)(i + 1); }
+    if (k != nvals) return false;
+    h.size[k] = 0; h.count = k;
+    int code = 0; k = 0;
+    for (int j = 1; j <= 16; ++j) {
+        h.delta[j] = k - code;
+        if (h.size[k] == j) { while (h.size[k] == j) h.code[k++] = (uint16_t)(code++); if (code - 1 >= (1 << j)) return false; }
+        h.maxcode[j] = code << (16 - j);
+        code <<= 1;
+    }
+    h.maxcode[17] = 0x7fffffff;
+    std::memcpy(h.value, vals, (size_t)nvals);
+    h.ok = true;
+    return true;
+}
+struct JBits {
+    const uint8_t* p; const uint8_t* end; uint32_t acc = 0; int cnt = 0; int marker = -1; bool overrun = false;
+    void grow()
+    {
+        while (cnt <= 24) {
+            int b = 0;
+            if (marker < 0 && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    int c = p < end ? *p : 0xD9;
+                    while (c == 0xFF && p + 1 < end) { ++p; c = *p; }
+                    if (c == 0) ++p;                    // stuffed zero
+                    else { marker = c; ++p; b = 0; }   // a marker ends the entropy-coded segment: feed zeros from here on
+                }
+            } else if (marker < 0) overrun = true;
+            acc |= (uint32_t)b << (24 - cnt); cnt += 8;
+        }
+    }
+    int get(int n) { if (n == 0) return 0; if (cnt < n) grow(); uint32_t v = acc >> (32 - n); acc <<= n; cnt -= n; return (int)v; }
+    int decode(const JHuff& h)
+    {
+        if (cnt < 16) grow();
+        uint32_t top = acc >> 16; int len = 1;
+        while (len <= 16 && (int)top >= h.maxcode[len]) ++len;
+        if (len > 16) return -1;
+        int idx = (int)(acc >> (32 - len)) + h.delta[len];
+        if (idx < 0 || idx >= h.count) return -1;
+        acc <<= len; cnt -= len;
+        return h.value[idx];
+    }
+    static int extend(int v, int bits) { return v < (1 << (bits - 1)) ? v - (1 << bits) + 1 : v; }
+    void reset() { acc = 0; cnt = 0; marker = -1; }
+};
+inline uint8_t jclamp(long long x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// 64-bit temporaries: identical to the 32-bit original on every valid stream, and no signed overflow on corrupted coefficients
+#define JF2F(x) ((long long)(((x) * 4096 + 0.5)))
+#define JIDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                        \
+    long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                        \
+    p2 = s2; p3 = s6; p1 = (p2 + p3) * JF2F(0.5411961f);                                                 \
+    t2 = p1 + p3 * JF2F(-1.847759065f); t3 = p1 + p2 * JF2F(0.765366865f);                               \
+    p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                      \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                              \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                  \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2; p5 = (p3 + p4) * JF2F(1.175875602f);         \
+    t0 = t0 * JF2F(0.298631336f); t1 = t1 * JF2F(2.053119869f); t2 = t2 * JF2F(3.072711026f); t3 = t3 * JF2F(1.501321110f); \
+    p1 = p5 + p1 * JF2F(-0.899976223f); p2 = p5 + p2 * JF2F(-2.562915447f);                              \
+    p3 = p3 * JF2F(-1.961570560f); p4 = p4 * JF2F(-0.390180644f);                                        \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+void jidct_block(uint8_t* out, size_t stride, const short d[64])
+{
+    long long val[64];
+    for (int i = 0; i < 8; ++i) {
+        const short* c = d + i; long long* v = val + i;
+        if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+            long long dc = c[0] * 4; v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+        } else {
+            JIDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    for (int i = 0; i < 8; ++i) {
+        const long long* v = val + 8 * i; uint8_t* o = out + stride * (size_t)i;
+        JIDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        const long long bias = 65536 + (128 << 17);
+        x0 += bias; x1 += bias; x2 += bias; x3 += bias;
+        o[0] = jclamp((x0 + t3) >> 17); o[7] = jclamp((x0 - t3) >> 17); o[1] = jclamp((x1 + t2) >> 17); o[6] = jclamp((x1 - t2) >> 17);
+        o[2] = jclamp((x2 + t1) >> 17); o[5] = jclamp((x2 - t1) >> 17); o[3] = jclamp((x3 + t0) >> 17); o[4] = jclamp((x3 - t0) >> 17);
+    }
+}
+struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dcPred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data; };
+// one output row of a component at full resolution
+void jresample(const JComp& c, int hs, int vs, const uint8_t* nearRow, const uint8_t* farRow, int wLores, uint8_t* out)
+{
+    if (hs == 1 && vs == 1) { std::memcpy(out, nearRow, (size_t)wLores); return; }
+    if (hs == 1 && vs == 2) { for (int i = 0; i < wLores; ++i) out[i] = (uint8_t)((3 * nearRow[i] + farRow[i] + 2) >> 2); return; }
+    if (hs == 2 && vs == 1) {
+        const uint8_t* in = nearRow; int w = wLores;
+        if (w == 1) { out[0] = out[1] = in[0]; return; }
+        out[0] = in[0]; out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+        int i;
+        for (i = 1; i < w - 1; ++i) { int n = 3 * in[i] + 2; out[i * 2] = (uint8_t)((n + in[i - 1]) >> 2); out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2); }
+        out[i * 2] = (uint8_t)((in[w - 2] * 3 + in[w - 1] + 2) >> 2); out[i * 2 + 1] = in[w - 1];
+        return;
+    }
+    if (hs == 2 && vs == 2) {
+        int w = wLores;
+        if (w == 1) { out[0] = out[1] = (uint8_t)((3 * nearRow[0] + farRow[0] + 2) >> 2); return; }
+        int t1 = 3 * nearRow[0] + farRow[0];
+        out[0] = (uint8_t)((t1 + 2) >> 2);
+        for (int i = 1; i < w; ++i) { int t0 = t1; t1 = 3 * nearRow[i] + farRow[i]; out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4); out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4); }
+        out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+        return;
+    }
+    for (int i = 0; i < wLores; ++i) for (int j = 0; j < hs; ++j) out[i * hs + j] = nearRow[i];     // other ratios: nearest
+    (void)c;
+}
+} // namespace
+
+bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
+{
+    if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) { err = "not a JPEG"; return false; }
+    uint16_t quant[4][64]; bool haveQuant[4] = { false, false, false, false };
+    JHuff dcTab[4], acTab[4];
+    std::vector<JComp> comps; int width = 0, height = 0, hmax = 1, vmax = 1, restart = 0, adobeTransform = -1; bool sawSOF = false, decoded = false;
+    size_t pos = 2;
+    auto u16 = [&](size_t o) { return (int)((data[o] << 8) | data[o + 1]); };
+    while (pos + 4 <= n) {
+        if (data[pos] != 0xFF) { err = "JPEG marker expected"; return false; }
+        int m = data[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD9) break;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) { err = "JPEG truncated"; return false; }
+        int len = u16(pos);
+        if (len < 2 || pos + (size_t)len > n) { err = "JPEG segment overruns the file"; return false; }
+        const uint8_t* seg = data + pos + 2; int sl = len - 2;
+        if (m == 0xDB) {
+            while (sl > 0) {
+                int pq = seg[0] >> 4, tq = seg[0] & 15;
+                if (tq > 3 || pq > 1 || sl < 1 + 64 * (pq + 1)) { err = "bad DQT"; return false; }
+                for (int i = 0; i < 64; ++i) quant[tq][kDezigzag[i]] = (uint16_t)(pq ? ((seg[1 + 2 * i] << 8) | seg[2 + 2 * i]) : seg[1 + i]);
+                haveQuant[tq] = true;
+                seg += 1 + 64 * (pq + 1); sl -= 1 + 64 * (pq + 1);
+            }
+        } else if (m == 0xC4) {
+            while (sl > 0) {
+                if (sl < 17) { err = "bad DHT"; return false; }
+                int tc = seg[0] >> 4, th = seg[0] & 15, total = 0;
+                for (int i = 0; i < 16; ++i) total += seg[1 + i];
+                if (tc > 1 || th > 3 || total > 256 || sl < 17 + total) { err = "bad DHT"; return false; }
+                if (!jhuff_build(tc ? acTab[th] : dcTab[th], seg + 1, seg + 17, total)) { err = "bad Huffman table"; return false; }
+                seg += 17 + total; sl -= 17 + total;
+            }
+        } else if (m == 0xDD) { if (sl < 2) { err = "bad DRI"; return false; } restart = (seg[0] << 8) | seg[1]; }
+        else if (m == 0xEE && sl >= 12 && !std::memcmp(seg, "Adobe", 5)) adobeTransform = seg[11];
+        else if (m == 0xC0 || m == 0xC1) {
+            if (sawSOF) { err = "JPEG with several frames"; return false; }
+            if (sl < 6 || seg[0] != 8) { err = "only 8-bit JPEG samples are supported"; return false; }
+            height = (seg[1] << 8) | seg[2]; width = (seg[3] << 8) | seg[4]; int nc = seg[5];
+            if (width <= 0 || height <= 0 || width > 32768 || height > 32768) { err = "bad JPEG dimensions"; return false; }
+            if (nc != 1 && nc != 3) { err = "JPEG with " + std::to_string(nc) + " components is not supported (CMYK / YCCK)"; return false; }
+            if (sl < 6 + 3 * nc) { err = "bad SOF"; return false; }
+            comps.resize((size_t)nc);
+            for (int i = 0; i < nc; ++i) {
+                JComp& c = comps[(size_t)i]; c.id = seg[6 + 3 * i]; c.h = seg[7 + 3 * i] >> 4; c.v = seg[7 + 3 * i] & 15; c.tq = seg[8 + 3 * i];
+                if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) { err = "bad JPEG sampling factors"; return false; }
+                hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v);
+            }
+            for (JComp& c : comps) if (hmax % c.h || vmax % c.v) { err = "unsupported JPEG sampling ratio"; return false; }
+            int mcuX = (width + 8 * hmax - 1) / (8 * hmax), mcuY = (height + 8 * vmax - 1) / (8 * vmax);
+            for (JComp& c : comps) {
+                c.x = (width * c.h + hmax - 1) / hmax; c.y = (height * c.v + vmax - 1) / vmax; c.w2 = mcuX * c.h * 8; c.h2 = mcuY * c.v * 8;
+                c.data.assign((size_t)c.w2 * c.h2 + 15, 0);
+            }
+            sawSOF = true;
+        } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) { err = m == 0xC2 ? "progressive JPEG is not supported (re-save as baseline, or use PNG / DDS)" : "unsupported JPEG coding process"; return false; }
+        else if (m == 0xDA) {
+            if (!sawSOF || sl < 1) { err = "SOS before SOF"; return false; }
+            int ns = seg[0];
+            if (ns < 1 || ns > (int)comps.size() || sl < 1 + 2 * ns + 3) { err = "bad SOS"; return false; }
+            std::vector<JComp*> scan;
+            for (int i = 0; i < ns; ++i) {
+                JComp* c = nullptr; for (JComp& k : comps) if (k.id == seg[1 + 2 * i]) c = &k;
+                if (!c) { err = "SOS names an unknown component"; return false; }
+                c->td = seg[2 + 2 * i] >> 4; c->ta = seg[2 + 2 * i] & 15;
+                if (c->td > 3 || c->ta > 3 || !dcTab[c->td].ok || !acTab[c->ta].ok || !haveQuant[c->tq]) { err = "scan uses an undefined table"; return false; }
+                scan.push_back(c);
+            }
+            if (seg[1 + 2 * ns] != 0 || seg[2 + 2 * ns] != 63) { err = "spectral selection in a sequential JPEG"; return false; }
+            JBits bits{ data + pos + (size_t)len, data + n };
+            for (JComp& c : comps) c.dcPred = 0;
+            auto block = [&](JComp& c, int bx, int by) -> bool {
+                short coef[64]; std::memset(coef, 0, sizeof coef);
+                int t = bits.decode(dcTab[c.td]);
+                if (t < 0 || t > 15) return false;
+                int diff = t ? JBits::extend(bits.get(t), t) : 0;
+                c.dcPred += diff; coef[0] = (short)(c.dcPred * quant[c.tq][0]);
+                for (int k = 1; k < 64;) {
+                    int rs = bits.decode(acTab[c.ta]);
+                    if (rs < 0) return false;
+                    int s = rs & 15, r = rs >> 4;
+                    if (s == 0) { if (rs != 0xF0) break; k += 16; }
+                    else { k += r; int zig = kDezigzag[k++]; coef[zig] = (short)(JBits::extend(bits.get(s), s) * quant[c.tq][zig]); }
+                }
+                jidct_block(c.data.data() + (size_t)c.w2 * (size_t)by * 8 + (size_t)bx * 8, (size_t)c.w2, coef);
+                return !bits.overrun;
+            };
+            int todo = restart ? restart : 0x7fffffff;
+            auto after_mcu = [&]() -> bool {
+                if (--todo <= 0) {
+                    if (bits.cnt < 24) bits.grow();
+                    if (bits.marker < 0xD0 || bits.marker > 0xD7) return true;      // no restart marker here: the scan data ended (or is damaged); decode what is left as zeros
+                    bits.reset(); for (JComp& c : comps) c.dcPred = 0; todo = restart;
+                }
+                return true;
+            };
+            bool ok = true;
+            if (ns == 1) {
+                JComp& c = *scan[0]; int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+                for (int j = 0; j < h && ok; ++j) for (int i = 0; i < w && ok; ++i) { ok = block(c, i, j) && after_mcu(); }
+            } else {
+                int mcuX = (width + 8 * hmax - 1) / (8 * hmax), mcuY = (height + 8 * vmax - 1) / (8 * vmax);
+                for (int j = 0; j < mcuY && ok; ++j) for (int i = 0; i < mcuX && ok; ++i) {
+                    for (JComp* c : scan) for (int y = 0; y < c->v && ok; ++y) for (int x = 0; x < c->h && ok; ++x) ok = block(*c, i * c->h + x, j * c->v + y);
+                    ok = ok && after_mcu();
+                }
+            }
+            if (!ok) { err = "corrupt JPEG entropy-coded data"; return false; }
+            decoded = true;
+            // continue after the entropy-coded segment: at the marker the bit reader stopped on, or scan forward for one
+            size_t q = (size_t)(bits.p - data);
+            if (bits.marker >= 0) { pos = q - 2; continue; }
+            while (q + 1 < n && !(data[q] == 0xFF && data[q + 1] != 0 && !(data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7))) ++q;
+            pos = q; continue;
+        }
+        pos += (size_t)len;
+    }
+    if (!sawSOF || !decoded) { err = "JPEG without image data"; return false; }
+    out.width = (uint32_t)width; out.height = (uint32_t)height; out.rgba.assign((size_t)width * height * 4, 255);
+    const size_t nc = comps.size();
+    std::vector<std::vector<uint8_t>> line(nc, std::vector<uint8_t>((size_t)width + 8 * 4 + 16));
+    struct Res { int hs, vs, ystep, wLores, ypos; const uint8_t* line0; const uint8_t* line1; };
+    std::vector<Res> res(nc);
+    for (size_t k = 0; k < nc; ++k) { const JComp& c = comps[k]; res[k] = { hmax / c.h, vmax / c.v, (vmax / c.v) >> 1, (width + hmax / c.h - 1) / (hmax / c.h), 0, c.data.data(), c.data.data() }; }
+    for (int j = 0; j < height; ++j) {
+        for (size_t k = 0; k < nc; ++k) {
+            Res& r = res[k]; const JComp& c = comps[k];
+            bool bot = r.ystep >= (r.vs >> 1);
+            jresample(c, r.hs, r.vs, bot ? r.line1 : r.line0, bot ? r.line0 : r.line1, r.wLores, line[k].data());
+            if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < c.y) r.line1 += c.w2; }
+        }
+        uint8_t* o = &out.rgba[(size_t)j * width * 4];
+        if (nc == 1) for (int i = 0; i < width; ++i) { o[4 * i] = o[4 * i + 1] = o[4 * i + 2] = line[0][(size_t)i]; }
+        else if (adobeTransform == 0) for (int i = 0; i < width; ++i) { o[4 * i] = line[0][(size_t)i]; o[4 * i + 1] = line[1][(size_t)i]; o[4 * i + 2] = line[2][(size_t)i]; }
+        else for (int i = 0; i < width; ++i) {
+            #define JFIX(x) (((int)((x) * 4096.0f + 0.5f)) << 8)
+            int yf = (line[0][(size_t)i] << 20) + (1 << 19), cr = line[2][(size_t)i] - 128, cb = line[1][(size_t)i] - 128;
+            int r = yf + cr * JFIX(1.40200f);
+            int g = yf + (cr * -JFIX(0.71414f)) + (int)(((unsigned)(cb * -JFIX(0.34414f))) & 0xffff0000u);
+            int b = yf + cb * JFIX(1.77200f);
+            o[4 * i] = jclamp(r >> 20); o[4 * i + 1] = jclamp(g >> 20); o[4 * i + 2] = jclamp(b >> 20);
+            #undef JFIX
+        }
+    }
+    return true;
+}
+
 bool DecodeImage(const uint8_t* data, size_t n, Image& out, std::string& err)
 {
     if (n >= 8 && data[0] == 0x89 && data[1] == 'P') return DecodePNG(data, n, out, err);
     if (n >= 4 && !std::memcmp(data, "DDS ", 4)) return DecodeDDS(data, n, out, err);
-    if (n >= 3 && data[0] == 0xFF && data[1] == 0xD8) { err = "JPEG images are not decoded (convert to PNG or DDS)"; return false; }
+    if (n >= 3 && data[0] == 0xFF && data[1] == 0xD8) return DecodeJPEG(data, n, out, err);
     if (n >= 12 && !std::memcmp(data + 1, "KTX 20", 6)) { err = "KTX2 images are not decoded"; return false; }
     err = "unrecognised image format";
     return false;

@@ -1,7 +1,7 @@
 // scene_fuzz -- robustness driver for the scene-format readers (they take files from outside): mutates seed inputs and feeds them to
 // the JSON parser, the image decoders, the cooked-mesh reader and the glTF loader. Built with -fsanitize=address,undefined by
 // `make fuzz` (CPU only); any crash, leak-free abort or sanitizer report fails the run. Not part of the product libraries.
-//   scene_fuzz <iterations> <seed> <file>...      (files are told apart by extension: .png .dds .json .gltf .glb .bin)
+//   scene_fuzz <iterations> <seed> <file>...      (files are told apart by extension: .png .jpg .dds .json .scene.json .gltf .glb .bin)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,7 +92,7 @@ int main(int argc, char** argv)
         for (int it = 0; it < iterations; ++it) {
             std::vector<uint8_t> m = it == 0 ? seed : ((ext == ".gltf" || ext == ".json" || ext == ".scene.json") && (rnd() & 1) ? mutate_json_numbers(seed) : mutate(seed));
             bool ok = false; std::string err;
-            if (ext == ".png" || ext == ".dds") { hobbyrt::Image img; ok = hobbyrt::DecodeImage(m.data(), m.size(), img, err); if (ok && img.rgba.size() != (size_t)img.width * img.height * 4) return 1; }
+            if (ext == ".png" || ext == ".dds" || ext == ".jpg") { hobbyrt::Image img; ok = hobbyrt::DecodeImage(m.data(), m.size(), img, err); if (ok && img.rgba.size() != (size_t)img.width * img.height * 4) return 1; }
             else if (ext == ".json") { hobbyrt::json::Value v; ok = hobbyrt::json::parse(reinterpret_cast<const char*>(m.data()), m.size(), v, err); }
             else {
                 // file-based readers: write the mutant next to the seed's side files (buffers, images) so references still resolve

@@ -768,6 +768,8 @@ def load(path):
         full = os.path.join(t["dir"], urllib.parse.unquote(t["uri"])) if t["uri"] and not t["uri"].startswith("data:") else None
         if full and os.path.exists(full) and open(full, "rb").read(8)[:4] == b"\x89PNG":
             t["pixels"] = decode_png(open(full, "rb").read()); t["bindless"] = nxt; nxt += 1
+        elif full and os.path.exists(full) and open(full, "rb").read(2) == b"\xff\xd8":
+            t["pixels"] = decode_jpeg(open(full, "rb").read()); t["bindless"] = nxt; nxt += 1
     out_mats = np.zeros(len(materials), MaterialConstants)
     for i, (g, refs) in enumerate(zip(materials, mat_cpu)):
         for k in refs:
@@ -808,3 +810,268 @@ def load(path):
             "mesh_data": np.array(sc.mesh_data, MeshData) if sc.mesh_data else np.zeros(0, MeshData), "instances": instances, "materials": out_mats,
             "lights": gpu_lights, "textures": textures, "sun_direction": sun, "camera": camera, "camera_count": len(cameras),
             "sun_angular_size": float(f32(lights[-1]["angular"]))}
+
+
+# ---------------------------------------------------------------- JPEG (baseline sequential), stb_image's integer pipeline restated
+_DEZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+             29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _f2f(x):
+    return int(x * 4096 + 0.5)
+
+
+def _idct_1d(s):
+    s0, s1, s2, s3, s4, s5, s6, s7 = s
+    p2, p3 = s2, s6
+    p1 = (p2 + p3) * _f2f(0.5411961)
+    t2 = p1 + p3 * _f2f(-1.847759065); t3 = p1 + p2 * _f2f(0.765366865)
+    p2, p3 = s0, s4
+    t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096
+    x0, x3, x1, x2 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+    t0, t1, t2, t3 = s7, s5, s3, s1
+    p3, p4, p1, p2 = t0 + t2, t1 + t3, t0 + t3, t1 + t2
+    p5 = (p3 + p4) * _f2f(1.175875602)
+    t0 *= _f2f(0.298631336); t1 *= _f2f(2.053119869); t2 *= _f2f(3.072711026); t3 *= _f2f(1.501321110)
+    p1 = p5 + p1 * _f2f(-0.899976223); p2 = p5 + p2 * _f2f(-2.562915447)
+    p3 *= _f2f(-1.961570560); p4 *= _f2f(-0.390180644)
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3
+    return x0, x1, x2, x3, t0, t1, t2, t3
+
+
+def _idct_block(d):
+    val = [0] * 64
+    for i in range(8):
+        col = [d[i + 8 * k] for k in range(8)]
+        if not any(col[1:]):
+            for k in range(8):
+                val[i + 8 * k] = col[0] * 4
+        else:
+            x0, x1, x2, x3, t0, t1, t2, t3 = _idct_1d(col)
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512
+            val[i] = (x0 + t3) >> 10; val[i + 56] = (x0 - t3) >> 10; val[i + 8] = (x1 + t2) >> 10; val[i + 48] = (x1 - t2) >> 10
+            val[i + 16] = (x2 + t1) >> 10; val[i + 40] = (x2 - t1) >> 10; val[i + 24] = (x3 + t0) >> 10; val[i + 32] = (x3 - t0) >> 10
+    out = np.zeros((8, 8), np.uint8)
+    cl = lambda v: 0 if v < 0 else (255 if v > 255 else v)  # noqa: E731
+    for i in range(8):
+        x0, x1, x2, x3, t0, t1, t2, t3 = _idct_1d(val[8 * i:8 * i + 8])
+        b = 65536 + (128 << 17)
+        x0 += b; x1 += b; x2 += b; x3 += b
+        out[i] = [cl((x0 + t3) >> 17), cl((x1 + t2) >> 17), cl((x2 + t1) >> 17), cl((x3 + t0) >> 17), cl((x3 - t0) >> 17), cl((x2 - t1) >> 17), cl((x1 - t2) >> 17), cl((x0 - t3) >> 17)]
+    return out
+
+
+def decode_jpeg(data):
+    assert data[:2] == b"\xff\xd8"
+    quant, dc_tab, ac_tab, comps = {}, {}, {}, []
+    width = height = restart = 0
+    adobe = -1
+    pos = 2
+    planes = None
+    while pos + 4 <= len(data):
+        assert data[pos] == 0xFF
+        m = data[pos + 1]
+        if m == 0xFF:
+            pos += 1; continue
+        pos += 2
+        if m == 0xD9:
+            break
+        if m == 0x01 or 0xD0 <= m <= 0xD7:
+            continue
+        ln = struct.unpack_from(">H", data, pos)[0]
+        seg = data[pos + 2:pos + ln]
+        if m == 0xDB:
+            while seg:
+                pq, tq = seg[0] >> 4, seg[0] & 15
+                vals = struct.unpack_from(">64H" if pq else "64B", seg, 1)
+                q = [0] * 64
+                for i in range(64):
+                    q[_DEZIGZAG[i]] = vals[i]
+                quant[tq] = q
+                seg = seg[1 + 64 * (pq + 1):]
+        elif m == 0xC4:
+            while seg:
+                tc, th = seg[0] >> 4, seg[0] & 15
+                counts = list(seg[1:17]); total = sum(counts)
+                vals = seg[17:17 + total]
+                table, code, k = {}, 0, 0
+                for length in range(1, 17):
+                    for _ in range(counts[length - 1]):
+                        table[(length, code)] = vals[k]; code += 1; k += 1
+                    code <<= 1
+                (ac_tab if tc else dc_tab)[th] = table
+                seg = seg[17 + total:]
+        elif m == 0xDD:
+            restart = struct.unpack(">H", seg[:2])[0]
+        elif m == 0xEE and seg[:5] == b"Adobe":
+            adobe = seg[11]
+        elif m in (0xC0, 0xC1):
+            _, height, width, nc = struct.unpack_from(">BHHB", seg, 0)
+            comps = [{"id": seg[6 + 3 * i], "h": seg[7 + 3 * i] >> 4, "v": seg[7 + 3 * i] & 15, "tq": seg[8 + 3 * i]} for i in range(nc)]
+            hmax = max(c["h"] for c in comps); vmax = max(c["v"] for c in comps)
+            mcu_x = (width + 8 * hmax - 1) // (8 * hmax); mcu_y = (height + 8 * vmax - 1) // (8 * vmax)
+            for c in comps:
+                c["x"] = (width * c["h"] + hmax - 1) // hmax; c["y"] = (height * c["v"] + vmax - 1) // vmax
+                c["plane"] = np.zeros((mcu_y * c["v"] * 8, mcu_x * c["h"] * 8), np.uint8)
+        elif m == 0xDA:
+            ns = seg[0]
+            scan = []
+            for i in range(ns):
+                c = next(k for k in comps if k["id"] == seg[1 + 2 * i])
+                c["td"], c["ta"] = seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15
+                scan.append(c)
+            # entropy-coded data up to the next non-RST marker, split at restart markers, byte stuffing removed
+            q = pos + ln
+            chunks, cur = [], bytearray()
+            while q < len(data):
+                b = data[q]
+                if b == 0xFF:
+                    nb = data[q + 1]
+                    if nb == 0:
+                        cur.append(0xFF); q += 2; continue
+                    if 0xD0 <= nb <= 0xD7:
+                        chunks.append(bytes(cur)); cur = bytearray(); q += 2; continue
+                    if nb == 0xFF:
+                        q += 1; continue
+                    break
+                cur.append(b); q += 1
+            chunks.append(bytes(cur))
+            state = {"chunk": 0, "bits": "", "off": 0}
+
+            def load_chunk():
+                state["bits"] = "".join(f"{b:08b}" for b in chunks[state["chunk"]]) + "0" * 64 if state["chunk"] < len(chunks) else "0" * 4096
+                state["off"] = 0
+            load_chunk()
+
+            def get(nb):
+                if nb == 0:
+                    return 0
+                s = state["bits"][state["off"]:state["off"] + nb]
+                s = s + "0" * (nb - len(s))
+                state["off"] += nb
+                return int(s, 2)
+
+            def decode(tab):
+                code = 0
+                for length in range(1, 17):
+                    code = (code << 1) | get(1)
+                    if (length, code) in tab:
+                        return tab[(length, code)]
+                raise ValueError("bad Huffman code")
+
+            def extend(v, nb):
+                return v - (1 << nb) + 1 if v < (1 << (nb - 1)) else v
+
+            for c in comps:
+                c["pred"] = 0
+
+            def block(c, bx, by):
+                coef = [0] * 64
+                t = decode(dc_tab[c["td"]])
+                c["pred"] += extend(get(t), t) if t else 0
+                coef[0] = int(np.int64(c["pred"] * quant[c["tq"]][0]).astype(np.int16))        # stored in a short, as in the product
+                k = 1
+                while k < 64:
+                    rs = decode(ac_tab[c["ta"]])
+                    s, r = rs & 15, rs >> 4
+                    if s == 0:
+                        if rs != 0xF0:
+                            break
+                        k += 16
+                    else:
+                        k += r
+                        zig = _DEZIGZAG[k] if k < 64 else 63
+                        k += 1
+                        coef[zig] = int(np.int64(extend(get(s), s) * quant[c["tq"]][zig]).astype(np.int16))
+                c["plane"][by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = _idct_block(coef)
+
+            todo = restart if restart else 1 << 30
+
+            def after_mcu():
+                nonlocal todo
+                todo -= 1
+                if todo <= 0:
+                    if state["chunk"] + 1 < len(chunks):
+                        state["chunk"] += 1; load_chunk()
+                        for c in comps:
+                            c["pred"] = 0
+                        todo = restart
+            if ns == 1:
+                c = scan[0]
+                for j in range((c["y"] + 7) >> 3):
+                    for i in range((c["x"] + 7) >> 3):
+                        block(c, i, j); after_mcu()
+            else:
+                for j in range(mcu_y):
+                    for i in range(mcu_x):
+                        for c in scan:
+                            for y in range(c["v"]):
+                                for x in range(c["h"]):
+                                    block(c, i * c["h"] + x, j * c["v"] + y)
+                        after_mcu()
+            planes = True
+            pos = q
+            continue
+        pos += ln
+    assert planes
+    out = np.full((height, width, 4), 255, np.uint8)
+    lines = []
+    for c in comps:
+        hs, vs = hmax // c["h"], vmax // c["v"]
+        w_lo = (width + hs - 1) // hs
+        P = c["plane"].astype(np.int32)
+        full = np.zeros((height, w_lo * hs + 2), np.int32)
+        ystep, ypos, l0, l1 = vs >> 1, 0, 0, 0
+        for j in range(height):
+            bot = ystep >= (vs >> 1)
+            near, far = (P[l1], P[l0]) if bot else (P[l0], P[l1])
+            if hs == 1 and vs == 1:
+                row = near[:w_lo].copy()
+            elif hs == 1 and vs == 2:
+                row = (3 * near[:w_lo] + far[:w_lo] + 2) >> 2
+            elif hs == 2 and vs == 1:
+                w = w_lo; row = np.zeros(2 * w, np.int32); a = near
+                if w == 1:
+                    row[0] = row[1] = a[0]
+                else:
+                    row[0] = a[0]; row[1] = (a[0] * 3 + a[1] + 2) >> 2
+                    for i in range(1, w - 1):
+                        nn = 3 * a[i] + 2
+                        row[2 * i] = (nn + a[i - 1]) >> 2; row[2 * i + 1] = (nn + a[i + 1]) >> 2
+                    row[2 * (w - 1)] = (a[w - 2] * 3 + a[w - 1] + 2) >> 2; row[2 * (w - 1) + 1] = a[w - 1]
+            elif hs == 2 and vs == 2:
+                w = w_lo; row = np.zeros(2 * w, np.int32)
+                if w == 1:
+                    row[0] = row[1] = (3 * near[0] + far[0] + 2) >> 2
+                else:
+                    t = 3 * near[:w] + far[:w]
+                    row[0] = (t[0] + 2) >> 2
+                    for i in range(1, w):
+                        row[2 * i - 1] = (3 * t[i - 1] + t[i] + 8) >> 4; row[2 * i] = (3 * t[i] + t[i - 1] + 8) >> 4
+                    row[2 * w - 1] = (t[w - 1] + 2) >> 2
+            else:
+                row = np.repeat(near[:w_lo], hs)
+            full[j, :len(row)] = row
+            ystep += 1
+            if ystep >= vs:
+                ystep = 0; l0 = l1; ypos += 1
+                if ypos < c["y"]:
+                    l1 += 1
+        lines.append(full[:, :width])
+    if len(comps) == 1:
+        out[..., 0] = out[..., 1] = out[..., 2] = lines[0]
+    elif adobe == 0:
+        for k in range(3):
+            out[..., k] = lines[k]
+    else:
+        fix = lambda x: int(np.float32(np.float32(x) * np.float32(4096.0) + np.float32(0.5))) << 8  # noqa: E731
+        y = lines[0].astype(np.int64); cb = lines[1].astype(np.int64) - 128; cr = lines[2].astype(np.int64) - 128
+        yf = (y << 20) + (1 << 19)
+        r = yf + cr * fix(1.40200)
+        gb = (cb * -fix(0.34414)) & 0xFFFF0000
+        gb = np.where(gb >= (1 << 31), gb - (1 << 32), gb)
+        g = yf + cr * -fix(0.71414) + gb
+        b = yf + cb * fix(1.77200)
+        for k, v in enumerate((r, g, b)):
+            out[..., k] = np.clip(v >> 20, 0, 255)
+    return out

@@ -284,3 +284,110 @@ def build_scene_json(dirpath):
     with open(path, "w") as f:
         json.dump(scene, f, indent=1)
     return path
+
+
+def write_jpeg(path, rgb, subsampling="444", qscale=2, restart=0, adobe_rgb=False):
+    """Minimal baseline JPEG writer for the decoder tests (this image has no JPEG encoder): float DCT, linear quantisation tables,
+    flat (fixed-length) Huffman codes declared in DHT. subsampling: 444 | 422 | 420 | 440 | gray. adobe_rgb: components stored as RGB with an
+    Adobe APP14 marker (transform 0)."""
+    from scipy.fft import dctn
+    zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+          29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    rgb = np.asarray(rgb, np.float64)
+    h, w = rgb.shape[:2]
+    if subsampling == "gray":
+        planes = [rgb[..., 0] * 0.299 + rgb[..., 1] * 0.587 + rgb[..., 2] * 0.114]; samp = [(1, 1)]
+    elif adobe_rgb:
+        planes = [rgb[..., 0], rgb[..., 1], rgb[..., 2]]; samp = [(1, 1)] * 3
+    else:
+        r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+        planes = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128, 0.5 * r - 0.418688 * g - 0.081312 * b + 128]
+        samp = {"444": [(1, 1), (1, 1), (1, 1)], "422": [(2, 1), (1, 1), (1, 1)], "420": [(2, 2), (1, 1), (1, 1)], "440": [(1, 2), (1, 1), (1, 1)]}[subsampling]
+    hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+    mcu_x, mcu_y = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    W, H = mcu_x * 8 * hmax, mcu_y * 8 * vmax
+    qt = [np.array([[1 + (i + j) * qscale for j in range(8)] for i in range(8)], np.float64), np.array([[2 + (i + j) * qscale * 2 for j in range(8)] for i in range(8)], np.float64)]
+    coefs = []
+    for k, (pl, (sh, sv)) in enumerate(zip(planes, samp)):
+        p = np.pad(pl, ((0, H - h), (0, W - w)), mode="edge")
+        fx, fy = hmax // sh, vmax // sv
+        p = p.reshape(H // fy, fy, W // fx, fx).mean(axis=(1, 3))
+        q = qt[0 if k == 0 else 1]
+        blocks = {}
+        for by in range(p.shape[0] // 8):
+            for bx in range(p.shape[1] // 8):
+                d = dctn(p[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0, type=2, norm="ortho")
+                blocks[(bx, by)] = np.rint(d / q).astype(int).reshape(-1)
+        coefs.append(blocks)
+    bits = []
+
+    def put(v, n):
+        for i in range(n - 1, -1, -1):
+            bits.append((v >> i) & 1)
+
+    def cat(v):
+        return 0 if v == 0 else int(abs(v)).bit_length()
+
+    def amp(v, n):
+        put(v if v >= 0 else v + (1 << n) - 1, n)
+    ac_syms = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
+    ac_code = {s: i for i, s in enumerate(ac_syms)}
+    out = bytearray(b"\xff\xd8")
+    if adobe_rgb:
+        out += b"\xff\xee" + struct.pack(">H", 14) + b"Adobe" + struct.pack(">HHHB", 100, 0, 0, 0)
+    for tq, q in enumerate(qt[:1 if len(planes) == 1 else 2]):
+        out += b"\xff\xdb" + struct.pack(">HB", 67, tq) + bytes(int(q.reshape(-1)[zz[i]]) for i in range(64))
+    out += b"\xff\xc0" + struct.pack(">HBHHB", 8 + 3 * len(planes), 8, h, w, len(planes))
+    for k, (sh, sv) in enumerate(samp):
+        out += bytes([k + 1, (sh << 4) | sv, 0 if k == 0 else 1])
+    out += b"\xff\xc4" + struct.pack(">HB", 19 + 12, 0x00) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(range(12))                       # DC: 12 symbols, 4-bit codes
+    out += b"\xff\xc4" + struct.pack(">HB", 19 + len(ac_syms), 0x10) + bytes([0] * 7 + [len(ac_syms)] + [0] * 8) + bytes(ac_syms)        # AC: 162 symbols, 8-bit codes
+    if restart:
+        out += b"\xff\xdd" + struct.pack(">HH", 4, restart)
+    out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(planes), len(planes)) + b"".join(bytes([k + 1, 0x00]) for k in range(len(planes))) + bytes([0, 63, 0])
+    pred = [0] * len(planes)
+    segments, count, rst = [], 0, 0
+
+    def flush():
+        nonlocal bits
+        while len(bits) % 8:
+            bits.append(1)
+        by = bytearray()
+        for i in range(0, len(bits), 8):
+            v = int("".join(map(str, bits[i:i + 8])), 2)
+            by.append(v)
+            if v == 0xFF:
+                by.append(0)
+        bits = []
+        return bytes(by)
+
+    for my in range(mcu_y):
+        for mx in range(mcu_x):
+            for k, (sh, sv) in enumerate(samp):
+                for y in range(sv):
+                    for x in range(sh):
+                        c = coefs[k][(mx * sh + x, my * sv + y)]
+                        diff = int(c[0]) - pred[k]; pred[k] = int(c[0])
+                        n = cat(diff); put(n, 4)
+                        if n:
+                            amp(diff, n)
+                        run = 0
+                        last = max([i for i in range(1, 64) if c[zz[i]] != 0], default=0)
+                        for i in range(1, last + 1):
+                            v = int(c[zz[i]])
+                            if v == 0:
+                                run += 1; continue
+                            while run > 15:
+                                put(ac_code[0xF0], 8); run -= 16
+                            n = min(cat(v), 10); v = max(-1023, min(1023, v))
+                            put(ac_code[(run << 4) | n], 8); amp(v, n); run = 0
+                        if last < 63:
+                            put(ac_code[0x00], 8)
+            count += 1
+            if restart and count % restart == 0 and not (my == mcu_y - 1 and mx == mcu_x - 1):
+                segments.append(flush() + bytes([0xFF, 0xD0 + (rst & 7)])); rst += 1
+                pred = [0] * len(planes)
+    segments.append(flush())
+    out += b"".join(segments) + b"\xff\xd9"
+    with open(path, "wb") as f:
+        f.write(bytes(out))

@@ -282,3 +282,54 @@ def test_scene_json_matches_oracle(tmp_path, luts):
     assert loaded.camera_count == 3 and any("EnvironmentLight" in w for w in loaded.warnings) and any("Marker" in w for w in loaded.warnings) and any("animations" in w for w in loaded.warnings)
     # the quad model's texture resolved through its sub-directory
     assert any(t is not None and t.shape == (4, 4, 4) for t in a.textures[11:])
+
+
+def test_jpeg_decoder(tmp_path):
+    """Baseline JPEG: the product decoder against the Python restatement of the same integer pipeline (IDCT, chroma upsampling, YCbCr->RGB
+    as in stb_image), on files written by the test encoder: all common subsamplings, odd sizes, restart intervals, grayscale, Adobe RGB."""
+    from gltf_helpers import write_jpeg
+    rng = np.random.default_rng(9)
+
+    def image(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(x / 5.0 + 0.3) * np.cos(y / 7.0), 128 + 90 * np.cos(x / 9.0) * np.cos(y / 4.0 + 1.0), 60 + 1.5 * x + 2.0 * y], -1)
+        return np.clip(img + rng.normal(0, 6, img.shape), 0, 255)
+
+    cases = [("444", 16, 16, 0, False), ("444", 37, 21, 3, False), ("422", 40, 17, 0, False), ("422", 9, 9, 1, False), ("420", 48, 32, 0, False), ("420", 23, 35, 2, False),
+             ("440", 20, 26, 0, False), ("gray", 33, 12, 0, False), ("444", 18, 11, 0, True), ("420", 1, 1, 0, False), ("420", 8, 3, 0, False)]
+    for k, (sub, w, h, restart, adobe) in enumerate(cases):
+        src = image(w, h)
+        p = str(tmp_path / f"j{k}.jpg")
+        write_jpeg(p, src, sub, qscale=1, restart=restart, adobe_rgb=adobe)
+        data = open(p, "rb").read()
+        got = scene_io.decode_image(data)
+        want = G.decode_jpeg(data)
+        assert got.shape == (h, w, 4) and (got[..., 3] == 255).all()
+        assert np.array_equal(got, want), (sub, w, h, restart)
+        ref = src if sub != "gray" else np.repeat((src[..., 0] * 0.299 + src[..., 1] * 0.587 + src[..., 2] * 0.114)[..., None], 3, -1)
+        mse = ((got[..., :3].astype(np.float64) - ref) ** 2).mean()
+        assert mse < (40.0 if sub in ("444", "gray") else 200.0), (sub, w, h, mse)       # a real decode, not just self-consistency
+    good = open(str(tmp_path / "j4.jpg"), "rb").read()
+    for bad in (good[:200], b"\xff\xd8\xff\xd9"):
+        with pytest.raises(scene_io.SceneFormatError):
+            scene_io.decode_image(bad)
+    with pytest.raises(scene_io.SceneFormatError) as e:
+        scene_io.decode_image(good.replace(b"\xff\xc0", b"\xff\xc2", 1))
+    assert "progressive" in str(e.value)
+
+
+def test_jpeg_texture_in_a_scene(tmp_path, luts):
+    from gltf_helpers import write_jpeg
+    y, x = np.mgrid[0:16, 0:24]
+    write_jpeg(str(tmp_path / "wood.jpg"), np.stack([100 + 5 * x, 80 + 3 * y, 40 + 0 * x], -1), "420")
+    a = Asset()
+    p, n, uv, i = grid(2, 2, 1.0)
+    a.add_primitive(0, p, i, n, uv, material=0)
+    a.j["images"] = [{"uri": "wood.jpg"}]; a.j["textures"] = [{"source": 0}]
+    a.j["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    a.j["nodes"] = [{"mesh": 0}]
+    path = str(tmp_path / "jpg.gltf")
+    a.write(path)
+    loaded = scene_io.load_gltf(path, luts)
+    _assert_same_scene(loaded, G.load(path))
+    assert loaded.arrays.textures[11].shape == (16, 24, 4) and loaded.arrays.materials["m_TextureFlags"][0] == 1 and not loaded.warnings
