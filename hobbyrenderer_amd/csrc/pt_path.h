@@ -407,38 +407,56 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     return SURFACE_SCATTER;
 }
 
-// PathTracer.hlsl:264-313. Returns false when the path ends.
-HRT_DEV bool shade_surface_b(PathState& ps, const SurfaceCarry& c, int bounce)
+// PathTracer.hlsl:264-313 in three pieces so that a wave can run the (rare, long) specular lobe for many paths at once:
+//   lobe_begin     Russian roulette :264-270, lobe pick :275-280 and what both lobes share (two draws, one sincos, one sqrt)
+//   lobe_diffuse   cosine-weighted sample + weight :295-304, ray advance :306-313
+//   lobe_specular  GGX-VNDF sample + weight :281-294, ray advance :306-313
+// shade_surface_b strings them together (validation megakernel, general wavefront variants). Values and operation order per path
+// are those of the reference in every arrangement.
+struct LobeDraw { float specProb, root, sp, cp; bool spec; };
+
+HRT_DEV bool lobe_begin(PathState& ps, const SurfaceCarry& c, int bounce, LobeDraw& ld)
 {
     if (bounce >= 2) {                                                            // Russian roulette :264-270
         float continuePr = hrt_saturate(maxcomp(ps.throughput));
         if (hrt_rng_next(&ps.rng) > continuePr) return false;
         ps.throughput = ps.throughput / continuePr;
     }
-    float specProb = hrt_clamp(lerp(c.Fr * 0.5f + 0.5f * c.metallic, 1.0f, c.metallic), 0.1f, 0.9f);   // :275
-    // lobe pick, then the work both lobes share (two draws, one sincos, one sqrt, the tangent frame, the final division) is done
-    // once for the whole wave instead of once per divergent branch; values and operation order per path are unchanged
-    const bool spec = hrt_rng_next(&ps.rng) < specProb;
+    ld.specProb = hrt_clamp(lerp(c.Fr * 0.5f + 0.5f * c.metallic, 1.0f, c.metallic), 0.1f, 0.9f);   // :275
+    ld.spec = hrt_rng_next(&ps.rng) < ld.specProb;
     const float ux = hrt_rng_next(&ps.rng), uy = hrt_rng_next(&ps.rng);
-    float sp, cp; hrt_sincos(2.0f * HRT_PI * (spec ? uy : ux), &sp, &cp);
-    const float root = hrt_sqrt(spec ? ux : uy);
-    f3 T, B; tangent_frame(c.N, T, B);
-    f3 newDir, numer;
-    if (spec) {
-        f3 H = sample_ggx_vndf_from(root, sp, cp, T, B, c.N, c.V, c.roughness);
-        newDir = reflect(-c.V, H);
-        if (dot(c.N, newDir) <= 0.0f) return false;
-        numer = eval_ggx_vndf_weight(c.F0, c.N, c.V, newDir, H, c.roughness);
-    } else {
-        newDir = sample_hemisphere_cosine_from(root, sp, cp, T, B, c.N);
-        if (dot(c.N, newDir) <= 0.0f) return false;
-        numer = c.baseColor * (1.0f - c.metallic);
-    }
-    f3 brdfWeight = numer / (spec ? specProb : 1.0f - specProb);
+    hrt_sincos(2.0f * HRT_PI * (ld.spec ? uy : ux), &ld.sp, &ld.cp);
+    ld.root = hrt_sqrt(ld.spec ? ux : uy);
+    return true;
+}
+HRT_DEV bool lobe_finish(PathState& ps, f3 worldPos, f3 N, f3 newDir, f3 numer, float denom)
+{
+    if (dot(N, newDir) <= 0.0f) return false;
+    f3 brdfWeight = numer / denom;
     ps.throughput = ps.throughput * brdfWeight;
     if (maxcomp(ps.throughput) < 0.01f) return false;                             // :306
-    ps.ray.o = c.worldPos; ps.ray.d = newDir; ps.ray.tmin = 1e-4f; ps.ray.tmax = 1e10f;   // :310-313
+    ps.ray.o = worldPos; ps.ray.d = newDir; ps.ray.tmin = 1e-4f; ps.ray.tmax = 1e10f;   // :310-313
     return true;
+}
+HRT_DEV bool lobe_diffuse(PathState& ps, f3 worldPos, f3 N, f3 baseColor, float metallic, const LobeDraw& ld)
+{
+    f3 T, B; tangent_frame(N, T, B);
+    f3 newDir = sample_hemisphere_cosine_from(ld.root, ld.sp, ld.cp, T, B, N);
+    return lobe_finish(ps, worldPos, N, newDir, baseColor * (1.0f - metallic), 1.0f - ld.specProb);
+}
+HRT_DEV bool lobe_specular(PathState& ps, f3 worldPos, f3 N, f3 V, f3 F0, float roughness, const LobeDraw& ld)
+{
+    f3 T, B; tangent_frame(N, T, B);
+    f3 H = sample_ggx_vndf_from(ld.root, ld.sp, ld.cp, T, B, N, V, roughness);
+    f3 newDir = reflect(-V, H);
+    if (dot(N, newDir) <= 0.0f) return false;       // before the weight, as in the reference (:289)
+    return lobe_finish(ps, worldPos, N, newDir, eval_ggx_vndf_weight(F0, N, V, newDir, H, roughness), ld.specProb);
+}
+HRT_DEV bool shade_surface_b(PathState& ps, const SurfaceCarry& c, int bounce)
+{
+    LobeDraw ld;
+    if (!lobe_begin(ps, c, bounce, ld)) return false;
+    return ld.spec ? lobe_specular(ps, c.worldPos, c.N, c.V, c.F0, c.roughness, ld) : lobe_diffuse(ps, c.worldPos, c.N, c.baseColor, c.metallic, ld);
 }
 
 // PathTracer.hlsl:315-328

@@ -324,6 +324,14 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
     const uint32_t in = parity, out = parity ^ 1u;
     const SceneView& s = a.scene;
+    // Deferred specular lobe (SIMPLE variant). On diffuse-dominated scenes ~10 % of the paths pick the GGX-VNDF lobe, a long branch that
+    // used to run in every iteration with ~6 active lanes. Those lanes now park what the lobe needs in a per-wave LDS ring (SoA, 128
+    // entries) and the wave runs the lobe for 64 of them at once (or for whatever is pending when a segment closes: their out-queue slots
+    // belong to that segment). Per path the arithmetic is unchanged.
+    extern __shared__ __attribute__((aligned(16))) char shadeSmem[];
+    constexpr uint32_t kRing = 128, kRingFields = 23;
+    float* const ring = reinterpret_cast<float*>(shadeSmem) + (size_t)(threadIdx.x >> 6) * kRing * kRingFields;
+    uint32_t ringHead = 0, pending = 0;
     // The wave works through its segments (gw, gw + totalWaves, ...) as one stream of 64-lane iterations: when the open segment A
     // has fewer than 64 entries left, the remaining lanes take the first entries of the next non-empty segment B, so only the wave's
     // last iteration is partially filled (after compaction a 256-slot segment holds ~207 / 168 / 136 paths at bounces 1 / 2 / 3: one
@@ -358,7 +366,9 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                 else segB = probe;          // no further segment: remembered so that the cursor below ends the loop
             }
             const bool inA = lane < takeA;
-            bool valid = lane < takeA + takeB, alive = false;
+            uint32_t outCountB = 0, shCountB = 0;
+            bool valid = lane < takeA + takeB, alive = false, wantDefer = false;
+            LobeDraw ld; ld.spec = false; ld.specProb = 0.0f; ld.root = 0.0f; ld.sp = 0.0f; ld.cp = 0.0f;
             uint32_t nNee = 0, smp = 0;
             PathState ps; f3 neeT = mk3(0.0f, 0.0f, 0.0f);
             NeeBuf<MAXL> nee; SurfaceCarry carry;
@@ -387,7 +397,15 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                         emissiveTerm = ps.radiance;
                         if (emissiveTerm.x != 0.0f || emissiveTerm.y != 0.0f || emissiveTerm.z != 0.0f) { addRadiance = true; add = emissiveTerm; }
                         neeT = ps.throughput;
-                        alive = shade_surface_b(ps, carry, bounce);
+                        // the sample drawn at the last bounce is never traced (the bounce loop ends, PathTracer.hlsl:90): nothing of it is observable
+                        if (!lastBounce) {
+                            if (SIMPLE) {
+                                if (lobe_begin(ps, carry, bounce, ld)) {
+                                    if (ld.spec) wantDefer = true;
+                                    else alive = lobe_diffuse(ps, carry.worldPos, carry.N, carry.baseColor, carry.metallic, ld);
+                                }
+                            } else alive = shade_surface_b(ps, carry, bounce);
+                        }
                     }
                 } else {
                     miss_sky(s, cb, ps, bounce);   // ps.radiance = throughput * sky
@@ -426,14 +444,55 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConst
                 for (int j = 0; j < MAXL; ++j)
                     if ((uint32_t)j < nNee) a.b.shL[(size_t)e * a.maxLights + j] = make_float4(nee.ux[j], nee.uy[j], __uint_as_float(nee.light[j]), 0.0f);
             }
-            // ---- advance the cursor
             outCount += (uint32_t)__popcll(mA); shCount += (uint32_t)__popcll(msA);
+            outCountB = (uint32_t)__popcll(mB); shCountB = (uint32_t)__popcll(msB);
+            if (SIMPLE) {
+                // ---- park the lanes that picked the specular lobe
+                const unsigned long long md = __ballot(wantDefer);
+                if (wantDefer) {
+                    float* e = ring + ((ringHead + pending + prefix_rank(md)) & (kRing - 1u));
+                    e[0 * kRing] = carry.N.x; e[1 * kRing] = carry.N.y; e[2 * kRing] = carry.N.z;
+                    e[3 * kRing] = carry.V.x; e[4 * kRing] = carry.V.y; e[5 * kRing] = carry.V.z;
+                    e[6 * kRing] = carry.F0.x; e[7 * kRing] = carry.F0.y; e[8 * kRing] = carry.F0.z;
+                    e[9 * kRing] = carry.roughness; e[10 * kRing] = ld.root; e[11 * kRing] = ld.sp; e[12 * kRing] = ld.cp; e[13 * kRing] = ld.specProb;
+                    e[14 * kRing] = carry.worldPos.x; e[15 * kRing] = carry.worldPos.y; e[16 * kRing] = carry.worldPos.z;
+                    e[17 * kRing] = ps.throughput.x; e[18 * kRing] = ps.throughput.y; e[19 * kRing] = ps.throughput.z;
+                    e[20 * kRing] = __uint_as_float(ps.rng); e[21 * kRing] = __uint_as_float(smp); e[22 * kRing] = inA ? 1.0f : 0.0f;
+                }
+                pending += (uint32_t)__popcll(md);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                // ---- run the lobe for 64 parked paths at once; when segment A closes, for everything that is parked
+                while (pending >= 64u || (endsA && pending)) {
+                    const uint32_t n = pending < 64u ? pending : 64u;
+                    bool alive2 = false, tagA = true; PathState q; uint32_t smp2 = 0;
+                    if (lane < n) {
+                        const float* e = ring + ((ringHead + lane) & (kRing - 1u));
+                        f3 N = mk3(e[0 * kRing], e[1 * kRing], e[2 * kRing]), V = mk3(e[3 * kRing], e[4 * kRing], e[5 * kRing]), F0 = mk3(e[6 * kRing], e[7 * kRing], e[8 * kRing]);
+                        LobeDraw d2; d2.spec = true; d2.root = e[10 * kRing]; d2.sp = e[11 * kRing]; d2.cp = e[12 * kRing]; d2.specProb = e[13 * kRing];
+                        f3 wp = mk3(e[14 * kRing], e[15 * kRing], e[16 * kRing]);
+                        q.throughput = mk3(e[17 * kRing], e[18 * kRing], e[19 * kRing]); q.rng = __float_as_uint(e[20 * kRing]); smp2 = __float_as_uint(e[21 * kRing]);
+                        tagA = e[22 * kRing] != 0.0f;
+                        alive2 = lobe_specular(q, wp, N, V, F0, e[9 * kRing], d2);
+                    }
+                    const unsigned long long m2A = __ballot(alive2 && tagA), m2B = __ballot(alive2 && !tagA);
+                    if (alive2) {
+                        uint32_t o = tagA ? baseA + outCount + prefix_rank(m2A) : baseB + outCountB + prefix_rank(m2B);
+                        a.b.rayO[out][o] = make_float4(q.ray.o.x, q.ray.o.y, q.ray.o.z, q.ray.tmin);
+                        a.b.rayD[out][o] = make_float4(q.ray.d.x, q.ray.d.y, q.ray.d.z, __uint_as_float(q.rng));
+                        a.b.thr[out][o] = make_float4(q.throughput.x, q.throughput.y, q.throughput.z, __uint_as_float(smp2));
+                    }
+                    outCount += (uint32_t)__popcll(m2A); outCountB += (uint32_t)__popcll(m2B);
+                    ringHead = (ringHead + n) & (kRing - 1u); pending -= n;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+            }
+            // ---- advance the cursor
             if (!endsA) next = nextA + takeA;
             else {
                 if (lane == 0) { a.b.pathCnt[out][segA] = outCount; a.b.shadowCnt[segA] = shCount; }
                 if (takeB) {                 // B becomes the open segment, already takeB entries in
                     seg = segB; segBase = baseB; cnt = cntB; next = takeB;
-                    outCount = (uint32_t)__popcll(mB); shCount = (uint32_t)__popcll(msB);
+                    outCount = outCountB; shCount = shCountB;
                     haveSeg = true;
                     if (next >= cnt) {       // B was short enough to end in the same iteration
                         if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
@@ -784,7 +843,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
-            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
