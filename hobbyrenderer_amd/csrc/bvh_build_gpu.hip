@@ -182,24 +182,41 @@ __global__ __launch_bounds__(kB) void k_hierarchy(BuildBuffers b, int shift)
     if (i == 0) b.parentOfInternal[0] = 0xFFFFFFFFu;
 }
 
-// ---- 4. bottom-up bounds: the second thread to reach a node merges its children's boxes
+// ---- 4. bottom-up bounds: the second thread to reach a node merges its children's boxes.
+// The hand-off between the two threads crosses CUs and XCDs (private L1s, per-XCD L2s that are not coherent with each other). A
+// __threadfence() pair per level would write back the whole XCD L2 every time (6.2 ms for 1.17 M triangles, 94 % of the build).
+// Instead every box written here is stored write-through with agent scope (sc1), drained (vmcnt 0) before the arrival counter is
+// bumped (agent-scope atomic), and the second arriver reads the sibling's box with agent-scope loads that bypass its L1: no fence.
+typedef unsigned long long __attribute__((address_space(1))) gu64;
+__device__ __forceinline__ void store_box_agent(float4* p, float4 v)
+{
+    gu64* q = (gu64*)p;
+    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_box_agent(const float4* p)
+{
+    gu64* q = (gu64*)p;
+    unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)c), 0.0f);
+}
 __global__ __launch_bounds__(kB) void k_fit(BuildBuffers b)
 {
     uint32_t leaf = blockIdx.x * kB + threadIdx.x;
     if (leaf >= b.triCount) return;
     uint32_t node = b.parentOfLeaf[leaf];
     while (node != 0xFFFFFFFFu) {
-        if (atomicAdd(&b.visit[node], 1u) == 0u) return;       // first arrival: the sibling subtree is not finished yet
-        __threadfence();
+        // arrival: everything this thread stored for the level below has been drained (end of the previous iteration)
+        if (__hip_atomic_fetch_add(&b.visit[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // first arrival: the sibling subtree is not finished yet
         float4 mn[2], mx[2];
         uint32_t ch[2] = { b.childL[node], b.childR[node] };
         for (int k = 0; k < 2; ++k) {
-            if (ch[k] & kLeafBit) { uint32_t g = b.valB[ch[k] & ~kLeafBit]; mn[k] = b.boxMinU[g]; mx[k] = b.boxMaxU[g]; }
-            else { mn[k] = b.nodeMin[ch[k]]; mx[k] = b.nodeMax[ch[k]]; }
+            if (ch[k] & kLeafBit) { uint32_t g = b.valB[ch[k] & ~kLeafBit]; mn[k] = b.boxMinU[g]; mx[k] = b.boxMaxU[g]; }   // written by k_setup: plain loads
+            else { mn[k] = load_box_agent(b.nodeMin + ch[k]); mx[k] = load_box_agent(b.nodeMax + ch[k]); }
         }
-        b.nodeMin[node] = make_float4(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z), 0.0f);
-        b.nodeMax[node] = make_float4(fmaxf(mx[0].x, mx[1].x), fmaxf(mx[0].y, mx[1].y), fmaxf(mx[0].z, mx[1].z), 0.0f);
-        __threadfence();
+        store_box_agent(b.nodeMin + node, make_float4(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z), 0.0f));
+        store_box_agent(b.nodeMax + node, make_float4(fmaxf(mx[0].x, mx[1].x), fmaxf(mx[0].y, mx[1].y), fmaxf(mx[0].z, mx[1].z), 0.0f));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have reached memory before the next arrival is signalled
         node = b.parentOfInternal[node];
     }
 }
@@ -448,37 +465,54 @@ struct Arena {          // one temporary allocation carved into aligned pieces
 
 } // namespace
 
-hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool usePloc, uint32_t maxStackDepth, const std::function<void*(size_t)>& sceneAlloc,
-                               hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+struct GpuBvhBuilder::Impl {
+    BuildBuffers b0{};                 // pointers as carved at prepare(); build() works on a copy (the PLOC path swaps order buffers)
+    void* scratch = nullptr; void* prim = nullptr;
+    GpuTri* tris = nullptr; GpuTriAttr* attrs = nullptr; GpuTriTangent* tangents = nullptr;
+    std::vector<InstRec> inst;         // static part filled at prepare(), world matrices per build()
+    size_t sortBytes = 0, scanBytes = 0, bytes = 0;
+    uint32_t n = 0;
+    int lastBudget = -1; bool lastUsePloc = false;   // hierarchy attempt that fitted the stacks at the previous build(): a rebuild starts there
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~Impl()
+    {
+        if (scratch) (void)hipFree(scratch);
+        if (tris) (void)hipFree(tris);
+        if (attrs) (void)hipFree(attrs);
+        if (tangents) (void)hipFree(tangents);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+GpuBvhBuilder::~GpuBvhBuilder() { delete p; }
+size_t GpuBvhBuilder::deviceBytes() const { return p ? p->bytes : 0; }
+
+hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hipStream_t stream, std::string& error)
 {
-    out = GpuBuiltBvh();
+    delete p; p = new Impl();
+    Impl& m = *p;
     hipError_t e;
-    // instance table + triangle prefix (host, O(instances))
-    std::vector<InstRec> inst(s.instanceCount);
+    // instance table + triangle prefix (host, O(instances)); mesh / material / opacity of an instance never change between rebuilds
+    m.inst.resize(s.instanceCount);
     uint64_t T = 0;
     for (uint32_t i = 0; i < s.instanceCount; ++i) {
         const HrptPerInstanceData& in = s.instances[i];
         const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
-        std::memcpy(inst[i].world, in.m_World, sizeof inst[i].world);
-        inst[i].indexOffset = md.m_IndexOffsets[0]; inst[i].triBase = (uint32_t)T; inst[i].material = in.m_MaterialIndex;
-        inst[i].opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+        m.inst[i].indexOffset = md.m_IndexOffsets[0]; m.inst[i].triBase = (uint32_t)T; m.inst[i].material = in.m_MaterialIndex;
+        m.inst[i].opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
         T += md.m_IndexCounts[0] / 3;
     }
     if (T < 8 || T >= (1ull << 29)) { error = "triangle count outside the GPU builder's range"; return hipErrorInvalidValue; }
-    const uint32_t n = (uint32_t)T;
-
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
-    auto cleanupEvents = [&]() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); };
+    const uint32_t n = m.n = (uint32_t)T;
+    if (hipEventCreate(&m.ev0) != hipSuccess || hipEventCreate(&m.ev1) != hipSuccess) { error = "hipEventCreate"; return hipErrorUnknown; }
 
     // rocPRIM scratch sizes
-    size_t sortBytes = 0, scanBytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sortBytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, stream);
-    (void)rocprim::exclusive_scan(nullptr, scanBytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), stream);
+    (void)rocprim::radix_sort_pairs(nullptr, m.sortBytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, stream);
+    (void)rocprim::exclusive_scan(nullptr, m.scanBytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), stream);
 
-    BuildBuffers b{};
+    BuildBuffers& b = m.b0;
     Arena A;
-    void* prim = nullptr; void* scratch = nullptr;
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 sizes the arena, pass 1 hands out pointers
         A.off = 0;
         b.triU = A.take<GpuTri>(n); b.boxMinU = A.take<float4>(n); b.boxMaxU = A.take<float4>(n);
@@ -493,32 +527,44 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool u
         b.pL = A.take<uint32_t>(2 * (size_t)n); b.pR = A.take<uint32_t>(2 * (size_t)n); b.finalPos = A.take<uint32_t>(2 * (size_t)n);
         b.clusterA = A.take<uint32_t>(n); b.clusterB = A.take<uint32_t>(n); b.nn = A.take<uint32_t>(n); b.mergeFlag = A.take<uint32_t>(n); b.validFlag = A.take<uint32_t>(n);
         b.mergeIdx = A.take<uint32_t>(n); b.validIdx = A.take<uint32_t>(n);
-        b.nodes = A.take<GpuNode>(n);            // staging: the dense count is known only after the scan
+        b.nodes = A.take<GpuNode>(n);            // the traversal kernels read the trees in place: a rebuild may change the node counts
         b.nodes4 = A.take<GpuNode4>(n / 2 + 1);
-        prim = A.take<char>(std::max(sortBytes, scanBytes));
+        m.prim = A.take<char>(std::max(m.sortBytes, m.scanBytes));
         char* vtx = A.take<char>((size_t)s.vertexCount * sizeof(HrptVertexQuantized));
         char* idx = A.take<char>((size_t)s.indexCount * 4);
-        char* ins = A.take<char>(inst.size() * sizeof(InstRec));
+        char* ins = A.take<char>(m.inst.size() * sizeof(InstRec));
         b.vertices = reinterpret_cast<const HrptVertexQuantized*>(vtx); b.indices = reinterpret_cast<const uint32_t*>(idx); b.inst = reinterpret_cast<const InstRec*>(ins);
         if (pass == 0) {
-            if ((e = hipMalloc(&scratch, A.off)) != hipSuccess) { error = "hipMalloc(GPU BVH build scratch)"; cleanupEvents(); return e; }
-            A.base = static_cast<char*>(scratch); A.cap = A.off;
+            if ((e = hipMalloc(&m.scratch, A.off)) != hipSuccess) { error = "hipMalloc(GPU BVH build arena)"; return e; }
+            A.base = static_cast<char*>(m.scratch); A.cap = A.off;
         }
     }
-    auto fail = [&](hipError_t err, const char* what) { error = what; (void)hipStreamSynchronize(stream); (void)hipFree(scratch); cleanupEvents(); return err; };
+    m.bytes = A.cap + (size_t)n * (sizeof(GpuTri) + sizeof(GpuTriAttr) + (needTangents ? sizeof(GpuTriTangent) : 0));
     b.instCount = s.instanceCount; b.triCount = n;
-    // outputs that live as long as the scene
-    b.tris = static_cast<GpuTri*>(sceneAlloc((size_t)n * sizeof(GpuTri)));
-    b.attrs = static_cast<GpuTriAttr*>(sceneAlloc((size_t)n * sizeof(GpuTriAttr)));
-    b.tangents = needTangents ? static_cast<GpuTriTangent*>(sceneAlloc((size_t)n * sizeof(GpuTriTangent))) : nullptr;
-    if (!b.tris || !b.attrs || (needTangents && !b.tangents)) return fail(hipErrorOutOfMemory, "hipMalloc(GPU BVH outputs)");
-
+    if ((e = hipMalloc((void**)&m.tris, (size_t)n * sizeof(GpuTri))) != hipSuccess || (e = hipMalloc((void**)&m.attrs, (size_t)n * sizeof(GpuTriAttr))) != hipSuccess ||
+        (needTangents && (e = hipMalloc((void**)&m.tangents, (size_t)n * sizeof(GpuTriTangent))) != hipSuccess)) { error = "hipMalloc(GPU BVH outputs)"; return hipErrorOutOfMemory; }
+    b.tris = m.tris; b.attrs = m.attrs; b.tangents = m.tangents;
     if ((e = hipMemcpyAsync(const_cast<HrptVertexQuantized*>(b.vertices), s.vertices, (size_t)s.vertexCount * sizeof(HrptVertexQuantized), hipMemcpyHostToDevice, stream)) != hipSuccess ||
         (e = hipMemcpyAsync(const_cast<uint32_t*>(b.indices), s.indices, (size_t)s.indexCount * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), inst.data(), inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
-        return fail(e, "hipMemcpyAsync(GPU BVH inputs)");
-    (void)hipEventRecord(ev0, stream);
+        (e = hipStreamSynchronize(stream)) != hipSuccess) { error = "hipMemcpyAsync(GPU BVH inputs)"; return e; }
+    return hipSuccess;
+}
 
+hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    out = GpuBuiltBvh();
+    if (!p || !p->scratch) { error = "GPU BVH builder not prepared"; return hipErrorInvalidValue; }
+    Impl& m = *p;
+    hipError_t e;
+    BuildBuffers b = m.b0;
+    const uint32_t n = m.n;
+    void* const prim = m.prim; size_t sortBytes = m.sortBytes, scanBytes = m.scanBytes;   // rocPRIM takes the size by non-const reference
+    for (size_t i = 0; i < m.inst.size(); ++i) std::memcpy(m.inst[i].world, instances[i].m_World, sizeof m.inst[i].world);
+    auto fail = [&](hipError_t err, const char* what) { error = what; (void)hipStreamSynchronize(stream); return err; };
+    if ((e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), m.inst.data(), m.inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
+        return fail(e, "hipMemcpyAsync(GPU BVH instances)");
+    hipEvent_t ev0 = m.ev0, ev1 = m.ev1;
+    (void)hipEventRecord(ev0, stream);
     const dim3 gT((n + kB - 1) / kB), blk(kB);
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, b.sceneBounds, b.flags);
     hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
@@ -531,7 +577,11 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool u
     if (const char* e = getenv("HRPT_GPU_BVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) maxLeafTris = (uint32_t)v; }
     const int attempts[] = { 64, 63, 48, 39, 30, 21, 12, 0 };          // 64 = PLOC
     uint32_t* const mortonOrder = b.valB;                              // leaf k of the radix tree = triangle mortonOrder[k]
+    if (m.lastUsePloc != usePloc) m.lastBudget = -1;
+    m.lastUsePloc = usePloc;
+    int fitted = -1;
     for (int budget : attempts) {
+        if (m.lastBudget >= 0 && budget > m.lastBudget) continue;      // too deep last time: moving instances rarely changes that, and every attempt costs a host round trip
         if (budget == 64) {
             if (!usePloc) continue;
             hipLaunchKernelGGL(k_ploc_init, gT, blk, 0, stream, b);
@@ -577,8 +627,9 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool u
         uint32_t d = 0;
         if ((e = hipMemcpyAsync(&d, b.flags + 1, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess || (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (depth)");
         maxDepthSeen = d; usedBits = budget == 64 ? 63 : budget; usedPloc = budget == 64;
-        if (d + 2 <= maxStackDepth) break;
+        if (d + 2 <= maxStackDepth) { fitted = budget; break; }
     }
+    m.lastBudget = fitted;
     const dim3 gN((nodeCount + kB - 1) / kB);
     if ((e = rocprim::exclusive_scan(prim, scanBytes, b.even, b.index4, 0u, nodeCount, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(even)");
     hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount);
@@ -586,6 +637,7 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool u
     (void)hipMemsetAsync(sahDev, 0, 4, stream);
     hipLaunchKernelGGL(k_sah, gN, blk, 0, stream, b, nodeCount, sahDev);
     hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
+    (void)hipEventRecord(ev1, stream);
     uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 }; float sahSum = 0.0f; GpuNode rootNode;
     if ((e = hipMemcpyAsync(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (e = hipMemcpyAsync(&sahSum, sahDev, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
@@ -595,18 +647,8 @@ hipError_t build_scene_bvh_gpu(const HrptSceneDesc& s, bool needTangents, bool u
         (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (emit)");
     if (flags[0]) return fail(hipErrorInvalidValue, "non-finite vertex position");
     const uint32_t node4Count = tail4[0] + tail4[1];
-    // compact copies of the node arrays into scene-lifetime allocations
-    GpuNode* nodes = static_cast<GpuNode*>(sceneAlloc((size_t)nodeCount * sizeof(GpuNode)));
-    GpuNode4* nodes4 = static_cast<GpuNode4*>(sceneAlloc((size_t)node4Count * sizeof(GpuNode4)));
-    if (!nodes || !nodes4) return fail(hipErrorOutOfMemory, "hipMalloc(GPU BVH nodes)");
-    if ((e = hipMemcpyAsync(nodes, b.nodes, (size_t)nodeCount * sizeof(GpuNode), hipMemcpyDeviceToDevice, stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(nodes4, b.nodes4, (size_t)node4Count * sizeof(GpuNode4), hipMemcpyDeviceToDevice, stream)) != hipSuccess) return fail(e, "hipMemcpyAsync(GPU BVH nodes)");
-    (void)hipEventRecord(ev1, stream);
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (finish)");
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev0, ev1);
-    (void)hipFree(scratch); cleanupEvents();
-
-    out.nodes = nodes; out.nodeCount = nodeCount; out.nodes4 = nodes4; out.node4Count = node4Count;
+    out.nodes = b.nodes; out.nodeCount = nodeCount; out.nodes4 = b.nodes4; out.node4Count = node4Count;
     out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n;
     {   // root box = union of the root's two child boxes
         float dx = std::max(rootNode.lmax[0], rootNode.rmax[0]) - std::min(rootNode.lmin[0], rootNode.rmin[0]);

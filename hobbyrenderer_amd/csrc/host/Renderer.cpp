@@ -37,8 +37,18 @@ int Renderer::Initialize(GraphicRHI* rhi)
     return HRPT_OK;
 }
 
+int Renderer::UploadDirtyInstanceTransforms()
+{
+    if (!m_Scene.AreInstanceTransformsDirty()) return HRPT_OK;
+    const uint32_t startIdx = m_Scene.m_InstanceDirtyRange.first, count = m_Scene.m_InstanceDirtyRange.second - startIdx + 1;
+    m_Scene.m_InstanceDirtyRange = { UINT32_MAX, 0 };       // "always reset after upload so the range never persists into the next frame"
+    if ((size_t)startIdx + count > m_Scene.m_InstanceData.size()) return HRPT_ERR_INVALID_ARGUMENT;   // the reference asserts (:932-938)
+    return hrpt_update_instances(m_RHI->m_Context, reinterpret_cast<const HrptPerInstanceData*>(m_Scene.m_InstanceData.data() + startIdx), startIdx, count);
+}
+
 int Renderer::RunPathTracerFrame()
 {
+    if (int r = UploadDirtyInstanceTransforms()) { m_LastStatus = r; return r; }   // before the renderers run, src/Renderer.cpp:497-498
     m_Scene.m_ViewPrev = m_Scene.m_View;
     m_Scene.m_Camera.FillPlanarViewConstants(m_Scene.m_View, (float)m_RHI->m_SwapchainExtent.x, (float)m_RHI->m_SwapchainExtent.y);
     if (m_FrameNumber == 0) m_Scene.m_ViewPrev = srrhi::PlanarViewConstants{};

@@ -22,6 +22,20 @@ void Scene::EnsureDefaultDirectionalLight()
     }
 }
 
+void Scene::SetNodeWorldTransform(int nodeIndex, const Matrix& world)
+{
+    // the per-node tail of Scene::Update (src/Scene.cpp:527-556): world transform, bounding sphere, instance records, dirty range
+    Node& node = m_Nodes.at((size_t)nodeIndex);
+    node.m_WorldTransform = world;
+    UpdateNodeBoundingSphere(nodeIndex);
+    for (uint32_t instIdx : node.m_InstanceIndices) {
+        srrhi::PerInstanceData& inst = m_InstanceData[instIdx];
+        inst.m_World = node.m_WorldTransform; inst.m_Center = node.m_Center; inst.m_Radius = node.m_Radius;
+        m_InstanceDirtyRange.first = std::min(m_InstanceDirtyRange.first, instIdx);
+        m_InstanceDirtyRange.second = std::max(m_InstanceDirtyRange.second, instIdx);
+    }
+}
+
 Vector3 Scene::GetSunDirection() const
 {
     const Light& dirLight = m_Lights.back();

@@ -2,6 +2,8 @@
 // registered renderers, run N frames of ReferencePathTracer mode, write the images. With --dump it also writes every
 // input of the boundary (scene arrays, per-frame constants) so the Python tests can feed the SAME bytes to the oracle.
 //   hobbyrt_pt_demo --scene cube|cornell | --gltf FILE [--mesh-cache]  --width W --height H --frames N --bounces B --out PREFIX [--dump] [--no-gpu]
+//                   [--move-node N DX DY DZ]   translate node N AFTER the scene was uploaded: the frames (and the dump) see the moved scene,
+//                                              the library gets it through Renderer::UploadDirtyInstanceTransforms -> hrpt_update_instances
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +31,7 @@ int main(int argc, char** argv)
     bool meshCache = false;
     uint32_t width = 256, height = 256, frames = 1, bounces = 1;
     bool dump = false, noGpu = false;
+    int moveNode = -1; float moveBy[3] = { 0.0f, 0.0f, 0.0f };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -36,6 +39,7 @@ int main(int argc, char** argv)
         else if (a == "--width") width = (uint32_t)std::atoi(next()); else if (a == "--height") height = (uint32_t)std::atoi(next());
         else if (a == "--frames") frames = (uint32_t)std::atoi(next()); else if (a == "--bounces") bounces = (uint32_t)std::atoi(next());
         else if (a == "--dump") dump = true; else if (a == "--no-gpu") noGpu = true;
+        else if (a == "--move-node") { moveNode = std::atoi(next()); for (float& v : moveBy) v = (float)std::atof(next()); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     Scene& s = g_Renderer.m_Scene;
@@ -58,6 +62,19 @@ int main(int argc, char** argv)
     if (GenerateAtmosphereLuts(s, 0) != HRPT_OK) { std::fprintf(stderr, "LUT generation failed\n"); return 1; }
     g_Renderer.m_PathTracerMaxBounces = bounces;
 
+    HrptContext* ctx = nullptr;
+    if (!noGpu) {
+        HrptDeviceDesc dd{ 0, HRPT_ABI_VERSION };
+        if (hrpt_create(&dd, &ctx) != HRPT_OK) { std::fprintf(stderr, "%s\n", hrpt_last_error(nullptr)); return 1; }
+        if (s.BuildAccelerationStructures(ctx) != HRPT_OK) { std::fprintf(stderr, "%s\n", hrpt_last_error(ctx)); return 1; }
+    }
+    if (moveNode >= 0) {
+        if (moveNode >= (int)s.m_Nodes.size()) { std::fprintf(stderr, "--move-node: the scene has %zu nodes\n", s.m_Nodes.size()); return 2; }
+        Matrix w = s.m_Nodes[(size_t)moveNode].m_WorldTransform;
+        w._41 += moveBy[0]; w._42 += moveBy[1]; w._43 += moveBy[2];
+        s.SetNodeWorldTransform(moveNode, w);
+        std::printf("node %d moved, dirty instance range [%u, %u]\n", moveNode, s.m_InstanceDirtyRange.first, s.m_InstanceDirtyRange.second);
+    }
     if (dump) {
         write_file(out + "_vertices.bin", s.m_Vertices.data(), s.m_Vertices.size() * sizeof(srrhi::VertexQuantized));
         write_file(out + "_indices.bin", s.m_Indices.data(), s.m_Indices.size() * 4);
@@ -74,10 +91,6 @@ int main(int argc, char** argv)
     }
     if (noGpu) return 0;
 
-    HrptContext* ctx = nullptr;
-    HrptDeviceDesc dd{ 0, HRPT_ABI_VERSION };
-    if (hrpt_create(&dd, &ctx) != HRPT_OK) { std::fprintf(stderr, "%s\n", hrpt_last_error(nullptr)); return 1; }
-    if (s.BuildAccelerationStructures(ctx) != HRPT_OK) { std::fprintf(stderr, "%s\n", hrpt_last_error(ctx)); return 1; }
     GraphicRHI rhi; rhi.m_SwapchainExtent = { width, height }; rhi.m_Context = ctx;
     if (g_Renderer.Initialize(&rhi) != HRPT_OK) { std::fprintf(stderr, "%s\n", hrpt_last_error(ctx)); return 1; }
     std::printf("renderer: %s\n", RendererRegistry::GetRenderer("PathTracerRenderer")->GetName());

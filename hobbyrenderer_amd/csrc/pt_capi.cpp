@@ -29,6 +29,11 @@ struct HrptContext {
     std::string err;
     // scene
     std::vector<void*> allocations;          // scene-lifetime device allocations
+    std::vector<void*> bvhAllocations;       // acceleration structure of the host builder + per-instance records: replaced by hrpt_update_instances
+    GpuBvhBuilder* gpuBuilder = nullptr;     // GPU builders: geometry + build buffers stay on the device for rebuilds
+    // host copy of what a rebuild needs (the reference's Scene keeps the same vectors: m_InstanceData, m_Vertices, m_Indices, m_MeshData)
+    std::vector<HrptVertexQuantized> keptVertices; std::vector<uint32_t> keptIndices; std::vector<HrptMeshData> keptMeshData;
+    std::vector<HrptPerInstanceData> keptInstances; std::vector<HrptMaterialConstants> keptMaterials;
     SceneView view{};
     bool haveScene = false;
     uint32_t bvhNodes = 0, bvhTris = 0;
@@ -80,22 +85,31 @@ static uint16_t float_to_half(float f)
     return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
 }
 
+static void free_acceleration(HrptContext* c, bool keepGpuBuilder)
+{
+    for (void* p : c->bvhAllocations) (void)hipFree(p);
+    c->bvhAllocations.clear();
+    if (!keepGpuBuilder) { delete c->gpuBuilder; c->gpuBuilder = nullptr; }
+}
+
 static void free_scene(HrptContext* c)
 {
+    free_acceleration(c, false);
     for (void* p : c->allocations) (void)hipFree(p);
     c->allocations.clear();
+    c->keptVertices.clear(); c->keptIndices.clear(); c->keptMeshData.clear(); c->keptInstances.clear(); c->keptMaterials.clear();
     c->haveScene = false;
     memset(&c->view, 0, sizeof c->view);
 }
 
 template <class T>
-static int upload(HrptContext* c, const T* host, size_t count, const T** dev)
+static int upload(HrptContext* c, const T* host, size_t count, const T** dev, std::vector<void*>* owner = nullptr)
 {
     *dev = nullptr;
     size_t bytes = count * sizeof(T);
     void* p = nullptr;
     HIP_TRY(c, hipMalloc(&p, bytes ? bytes : 16));
-    c->allocations.push_back(p);
+    (owner ? *owner : c->allocations).push_back(p);
     if (bytes) HIP_TRY(c, hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, c->stream));
     *dev = static_cast<const T*>(p);
     return HRPT_OK;
@@ -163,6 +177,83 @@ const char* hrpt_last_error(const HrptContext* c)
     return copy.c_str();
 }
 
+// The acceleration structure + the records derived from instance transforms (Scene::BuildAccelerationStructures, src/Scene.cpp:67-214),
+// written into `v`. First build of a scene or a rebuild after hrpt_update_instances (the GPU builder then keeps its device-resident
+// geometry and buffers).
+static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris, SceneView& v, bool firstBuild)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string berr;
+    int r;
+    c->buildInfo = HrptBuildInfo{};
+    c->buildInfo.requestedBuilder = (uint32_t)c->bvhBuilder;
+    free_acceleration(c, !firstBuild);
+    uint32_t maxDepth = 0, maxDepth4 = 0;
+    bool built = false;
+    if ((c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH || c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC) && sceneTris >= 8) {
+        // the whole build runs on the device; only the per-instance adjugate rows (O(instances)) are prepared on the host
+        GpuBuiltBvh g; std::string gerr;
+        hipError_t ge = hipSuccess;
+        if (!c->gpuBuilder) {
+            c->gpuBuilder = new GpuBvhBuilder();
+            ge = c->gpuBuilder->prepare(s, scene_needs_tangents(s), c->stream, gerr);
+        }
+        if (ge == hipSuccess) ge = c->gpuBuilder->build(s.instances, c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, c->stream, g, gerr);
+        if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
+            v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
+            v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
+            maxDepth = g.maxDepth; maxDepth4 = g.maxDepth4; built = true;
+            c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits; c->buildInfo.sahCost = g.sahCost;
+        } else {
+            // too deep for the traversal stacks (or a device error): drop the device-side builder and build on the host instead
+            delete c->gpuBuilder; c->gpuBuilder = nullptr;
+            if (ge == hipErrorInvalidValue && gerr == "non-finite vertex position") return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + gerr);
+            if (ge == hipErrorOutOfMemory) return fail(c, HRPT_ERR_OUT_OF_MEMORY, "acceleration structure: " + gerr);
+        }
+        if (built) {
+            std::vector<HostInstShade> shade; build_instance_shade(s, shade);
+            const HostInstShade* dis;
+            if ((r = upload(c, shade.data(), shade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
+            v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    if (!built) {
+        BuiltBvh bvh;
+        if (!build_scene_bvh(s, bvh, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+        std::vector<void*>* own = &c->bvhAllocations;
+        const HostNode* dn; const HostTri* dt;
+        if ((r = upload(c, bvh.nodes.data(), bvh.nodes.size(), &dn, own)) != HRPT_OK) return r;
+        if ((r = upload(c, bvh.tris.data(), bvh.tris.size(), &dt, own)) != HRPT_OK) return r;
+        v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
+        v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
+        v.rootLeaf = bvh.rootLeaf;
+        const HostNode4* dn4;
+        if ((r = upload(c, bvh.nodes4.data(), bvh.nodes4.size(), &dn4, own)) != HRPT_OK) return r;
+        v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)bvh.nodes4.size();
+        // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
+        // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
+        const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
+        if ((r = upload(c, bvh.attrs.data(), bvh.attrs.size(), &da, own)) != HRPT_OK) return r;
+        if ((r = upload(c, bvh.instShade.data(), bvh.instShade.size(), &dis, own)) != HRPT_OK) return r;
+        v.attrs = reinterpret_cast<const GpuTriAttr*>(da); v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+        v.tangents = nullptr;
+        if (!bvh.tangents.empty()) {
+            if ((r = upload(c, bvh.tangents.data(), bvh.tangents.size(), &dtg, own)) != HRPT_OK) return r;
+            v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the BuiltBvh staging vectors die at scope exit
+        maxDepth = bvh.maxDepth; maxDepth4 = bvh.maxDepth4;
+        c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.sahCost = bvh.sahCost;
+    }
+    c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = v.nodeCount; c->buildInfo.node4Count = v.node4Count;
+    c->buildInfo.maxDepth = maxDepth; c->buildInfo.maxDepth4 = maxDepth4;
+    c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
+    c->traits.bvhMaxDepth = maxDepth; c->traits.bvh4MaxDepth = maxDepth4;
+    return HRPT_OK;
+}
+
 static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
@@ -175,70 +266,10 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     if (!validate_scene(*s, sceneTris, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
-    const auto t0 = std::chrono::steady_clock::now();
-    c->buildInfo = HrptBuildInfo{};
-    c->buildInfo.requestedBuilder = (uint32_t)c->bvhBuilder;
-
+    c->traits = SceneTraits();
     SceneView v{};
     int r;
-    uint32_t maxDepth = 0, maxDepth4 = 0;
-    bool built = false;
-    if ((c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH || c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC) && sceneTris >= 8) {
-        // the whole build runs on the device; only the per-instance adjugate rows (O(instances)) are prepared on the host
-        GpuBuiltBvh g; std::string gerr;
-        size_t mark = c->allocations.size();
-        auto sceneAlloc = [c](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; c->allocations.push_back(p); return p; };
-        hipError_t ge = build_scene_bvh_gpu(*s, scene_needs_tangents(*s), c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, sceneAlloc, c->stream, g, gerr);
-        if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
-            v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
-            v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
-            maxDepth = g.maxDepth; maxDepth4 = g.maxDepth4; built = true;
-            c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits; c->buildInfo.sahCost = g.sahCost;
-        } else {
-            // too deep for the traversal stacks (or a device error): drop what was allocated and build on the host instead
-            for (size_t i = mark; i < c->allocations.size(); ++i) (void)hipFree(c->allocations[i]);
-            c->allocations.resize(mark);
-            if (ge == hipErrorInvalidValue && gerr == "non-finite vertex position") return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + gerr);
-            if (ge == hipErrorOutOfMemory) return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_upload_scene: " + gerr);
-        }
-        if (built) {
-            std::vector<HostInstShade> shade; build_instance_shade(*s, shade);
-            const HostInstShade* dis;
-            if ((r = upload(c, shade.data(), shade.size(), &dis)) != HRPT_OK) return r;
-            v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-    }
-    if (!built) {
-        BuiltBvh bvh;
-        if (!build_scene_bvh(*s, bvh, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
-        const HostNode* dn; const HostTri* dt;
-        if ((r = upload(c, bvh.nodes.data(), bvh.nodes.size(), &dn)) != HRPT_OK) return r;
-        if ((r = upload(c, bvh.tris.data(), bvh.tris.size(), &dt)) != HRPT_OK) return r;
-        v.nodes = reinterpret_cast<const GpuNode*>(dn); v.nodeCount = (uint32_t)bvh.nodes.size();
-        v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)bvh.tris.size();
-        v.rootLeaf = bvh.rootLeaf;
-        const HostNode4* dn4;
-        if ((r = upload(c, bvh.nodes4.data(), bvh.nodes4.size(), &dn4)) != HRPT_OK) return r;
-        v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)bvh.nodes4.size();
-        // The quantised vertex / index / mesh / instance buffers are consumed here: per-triangle attribute records and
-        // per-instance adjugate rows replace the per-hit GetTriangleVertices + UnpackVertex + MakeAdjugateMatrix work.
-        const HostTriAttr* da; const HostTriTangent* dtg; const HostInstShade* dis;
-        if ((r = upload(c, bvh.attrs.data(), bvh.attrs.size(), &da)) != HRPT_OK) return r;
-        if ((r = upload(c, bvh.instShade.data(), bvh.instShade.size(), &dis)) != HRPT_OK) return r;
-        v.attrs = reinterpret_cast<const GpuTriAttr*>(da); v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
-        v.tangents = nullptr;
-        if (!bvh.tangents.empty()) {
-            if ((r = upload(c, bvh.tangents.data(), bvh.tangents.size(), &dtg)) != HRPT_OK) return r;
-            v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
-        }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the BuiltBvh staging vectors die at scope exit
-        maxDepth = bvh.maxDepth; maxDepth4 = bvh.maxDepth4;
-        c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.sahCost = bvh.sahCost;
-    }
-    c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = v.nodeCount; c->buildInfo.node4Count = v.node4Count;
-    c->buildInfo.maxDepth = maxDepth; c->buildInfo.maxDepth4 = maxDepth4;
+    if ((r = build_acceleration(c, *s, sceneTris, v, true)) != HRPT_OK) return r;
     if ((r = upload(c, s->materials, s->materialCount, &v.materials)) != HRPT_OK) return r;
     if ((r = upload(c, s->lights, s->lightCount, &v.lights)) != HRPT_OK) return r;
     v.lightCount = s->lightCount;
@@ -266,9 +297,9 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // host staging vectors die at scope exit
 
     c->view = v; c->haveScene = true;
-    c->bvhNodes = v.nodeCount; c->bvhTris = v.triCount;
-    c->traits = SceneTraits();
-    c->traits.bvhMaxDepth = maxDepth; c->traits.bvh4MaxDepth = maxDepth4;
+    c->keptVertices.assign(s->vertices, s->vertices + s->vertexCount); c->keptIndices.assign(s->indices, s->indices + s->indexCount);
+    c->keptMeshData.assign(s->meshData, s->meshData + s->meshDataCount); c->keptInstances.assign(s->instances, s->instances + s->instanceCount);
+    c->keptMaterials.assign(s->materials, s->materials + s->materialCount);
     for (uint32_t i = 0; i < s->instanceCount; ++i) {
         const HrptMaterialConstants& m = s->materials[s->instances[i].m_MaterialIndex];
         if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;
@@ -278,6 +309,38 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
         if (m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) c->traits.hasTransmissiveOrBlend = true;
     }
     for (uint32_t i = 0; i < s->lightCount; ++i) if (s->lights[i].m_Type != HRPT_LIGHT_DIRECTIONAL) c->traits.directionalLightsOnly = false;
+    return HRPT_OK;
+}
+
+static int update_instances_impl(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_instances: no scene uploaded");
+    if (count == 0) return HRPT_OK;
+    if (!instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_instances: null instance array");
+    if ((uint64_t)firstInstance + count > c->keptInstances.size()) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_instances: range exceeds the scene's instance count");
+    for (uint32_t i = 0; i < count; ++i) {
+        const HrptPerInstanceData& now = instances[i]; const HrptPerInstanceData& was = c->keptInstances[firstInstance + i];
+        if (now.m_MeshDataIndex != was.m_MeshDataIndex || now.m_MaterialIndex != was.m_MaterialIndex || now.m_LODIndex != was.m_LODIndex)
+            return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_instances: mesh, material and LOD of an instance cannot change (upload the scene again)");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));        // frames in flight still traverse the old tree
+    std::memcpy(c->keptInstances.data() + firstInstance, instances, (size_t)count * sizeof(HrptPerInstanceData));
+    HrptSceneDesc s{};
+    s.vertices = c->keptVertices.data(); s.vertexCount = (uint32_t)c->keptVertices.size();
+    s.indices = c->keptIndices.data(); s.indexCount = (uint32_t)c->keptIndices.size();
+    s.meshData = c->keptMeshData.data(); s.meshDataCount = (uint32_t)c->keptMeshData.size();
+    s.instances = c->keptInstances.data(); s.instanceCount = (uint32_t)c->keptInstances.size();
+    s.materials = c->keptMaterials.data(); s.materialCount = (uint32_t)c->keptMaterials.size();
+    static const HrptGPULight noLight{};                 // lights play no part in the build; validate_scene only wants the array to exist
+    s.lights = &noLight; s.lightCount = 1;
+    uint64_t sceneTris = 0;
+    for (const HrptPerInstanceData& in : c->keptInstances) sceneTris += c->keptMeshData[in.m_MeshDataIndex].m_IndexCounts[0] / 3;
+    SceneView v = c->view;
+    int r = build_acceleration(c, s, sceneTris, v, false);
+    if (r != HRPT_OK) { c->haveScene = false; return r; }   // the old tree is gone: the scene has to be uploaded again
+    c->view = v;
     return HRPT_OK;
 }
 
@@ -356,6 +419,12 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     try { return upload_scene_impl(c, s); }
     catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_upload_scene: host allocation failed"); }
     catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_upload_scene: ") + e.what()); }
+}
+int hrpt_update_instances(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count)
+{
+    try { return update_instances_impl(c, instances, firstInstance, count); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_update_instances: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_update_instances: ") + e.what()); }
 }
 int hrpt_render(HrptContext* c, const HrptFrameParams* p)
 {

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -54,6 +54,7 @@ lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
 lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
 lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
+lib.hrpt_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_post_process.argtypes = [C.c_void_p, C.POINTER(S.PostParams)]
@@ -181,6 +182,12 @@ class PathTracerContext:
     def set_bvh_builder(self, builder):
         """S.BVH_BUILDER_HOST_SAH (default) or S.BVH_BUILDER_GPU_LBVH; used by the next upload_scene."""
         self._check(lib.hrpt_set_bvh_builder(self._h, int(builder)))
+
+    def update_instances(self, instances, first=0):
+        """New transforms for the instances [first, first + len(instances)) (PerInstanceData records); rebuilds the acceleration structure."""
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype.itemsize == 160, "PerInstanceData records expected"
+        self._check(lib.hrpt_update_instances(self._h, instances.ctypes.data, int(first), len(instances)))
 
     def build_info(self):
         bi = S.BuildInfo()

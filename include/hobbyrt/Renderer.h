@@ -89,6 +89,9 @@ struct Renderer {
     int Initialize(GraphicRHI* rhi);
     // One frame of ReferencePathTracer mode (src/Renderer.cpp:1276-1281 + camera update :510-519): returns HrptStatus
     int RunPathTracerFrame();
+    // src/Renderer.cpp:915-971: hands the scene's dirty instance range to the library (hrpt_update_instances: instance records +
+    // acceleration-structure rebuild, the reference's writeBuffer pair + TLASRenderer) and resets the range. Returns an HrptStatus.
+    int UploadDirtyInstanceTransforms();
     int m_LastStatus = 0;
 };
 extern Renderer g_Renderer;

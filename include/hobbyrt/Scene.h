@@ -8,6 +8,7 @@
 
 #include <cfloat>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../hobbyrt_pt.h"
@@ -100,6 +101,14 @@ public:
     void CreateAndUploadLightBuffer();
     // Replaces BLAS/TLAS build + buffer uploads: validates and uploads everything through the C ABI. Returns an HrptStatus.
     int BuildAccelerationStructures(HrptContext* context);
+
+    // Moving objects. The closed range of m_InstanceData entries whose transform changed since the last upload ({UINT32_MAX, 0} = clean),
+    // grown by Scene::Update's "Sync instances" step (src/Scene.cpp:536-556) and consumed by Renderer::UploadDirtyInstanceTransforms
+    // (src/Renderer.cpp:915-971). Animation evaluation itself is out of scope (the path tracer pauses animations,
+    // src/PathTracerRenderer.cpp:53); SetNodeWorldTransform is the "manual scene mutation" route the reference mentions (:920-923).
+    std::pair<uint32_t, uint32_t> m_InstanceDirtyRange{ UINT32_MAX, 0 };
+    bool AreInstanceTransformsDirty() const { return m_InstanceDirtyRange.first <= m_InstanceDirtyRange.second; }
+    void SetNodeWorldTransform(int nodeIndex, const Matrix& world);
 
     Vector3 GetSunDirection() const;
     void UpdateNodeBoundingSphere(int nodeIndex);   // node sphere = mesh sphere through the node's world transform

@@ -271,17 +271,29 @@ int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output
 #define HRPT_BVH_BUILDER_GPU_LBVH 1      /* Morton radix tree (Karras 2012): fastest build */
 #define HRPT_BVH_BUILDER_GPU_PLOC 2      /* Morton order + nearest-neighbour clustering (PLOC): better tree, a few times the LBVH build time;
                                             falls back to the LBVH hierarchy when its tree is too deep for the traversal stacks */
-int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene */
+int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene / hrpt_update_instances */
 typedef struct HrptBuildInfo {
     uint32_t requestedBuilder, usedBuilder;     /* HRPT_BVH_BUILDER_* */
-    float    buildMs;                           /* host wall time of the build inside hrpt_upload_scene (copies included) */
-    float    deviceBuildMs;                     /* GPU builder: device time, first kernel to last node copy; else 0 */
+    float    buildMs;                           /* host wall time of the last build inside hrpt_upload_scene / hrpt_update_instances (copies included) */
+    float    deviceBuildMs;                     /* GPU builder: device time, instance-table copy to last kernel; else 0 */
     uint32_t triangleCount, nodeCount, node4Count, maxDepth, maxDepth4;
     uint32_t mortonBits;                        /* GPU builder: Morton bits of the hierarchy (63 unless the full-code tree was too deep) */
     float    sahCost;                           /* surface-area-heuristic cost of the 2-wide tree: 1 + sum(area(child) * (inner ? 1 : triangles)) / area(root) */
     uint32_t pad[1];
 } HrptBuildInfo;                                /* 48 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
+
+/* Moving objects: writes instances[0..count) over the scene's instances [firstInstance, firstInstance + count) -- the closed dirty range
+ * Renderer::UploadDirtyInstanceTransforms copies into m_InstanceDataBuffer / m_RTInstanceDescBuffer (src/Renderer.cpp:924-967, fed by
+ * Scene::Update, src/Scene.cpp:536-556) -- and rebuilds the acceleration structure, the job of TLASRenderer's per-frame
+ * buildTopLevelAccelStructFromBuffer (src/CommonRenderers.cpp:234-246). Only m_World (and the unused m_PrevWorld / m_Center / m_Radius)
+ * may differ from the uploaded instance; a changed mesh, material or LOD index is HRPT_ERR_INVALID_ARGUMENT. With a GPU builder selected
+ * the geometry and all build buffers are already on the device: the call uploads count-independent O(instances) data and runs the build
+ * kernels (hrpt_get_build_info reports the rebuild); with the host builder the tree is rebuilt on the host from the library's copy of
+ * the scene. Waits for frames in flight, returns when the new tree is in place. The accumulation image is not touched: like
+ * PathTracerRenderer::Render's reset on a changed view matrix (src/PathTracerRenderer.cpp:41-50), restarting accumulation
+ * (firstAccumulationIndex = 0) is the caller's decision. If the rebuild fails the scene is unusable until hrpt_upload_scene. */
+int  hrpt_update_instances(HrptContext* ctx, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count);
 
 /* ---- in-process multi-GPU: one context per GPU inside ONE process ------------------------------------
  * Rank i of n has rendered the row band [i*H/n, (i+1)*H/n) of its accumulation image (HrptFrameParams::tile*; H must be a

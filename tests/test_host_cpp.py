@@ -57,6 +57,45 @@ def test_plugin_path_equals_oracle(tmp_path, luts, scene, w, h, frames, bounces)
     assert np.array_equal(out.view(np.uint32), oout.view(np.uint32))
 
 
+def test_cpp_moved_node_marks_the_dirty_range(tmp_path, luts):
+    """Scene::SetNodeWorldTransform (the instance-sync tail of Scene::Update, src/Scene.cpp:536-556): only the moved node's instance changes."""
+    base, _ = _dump(tmp_path, "cornell", 64, 36, ("--no-gpu",))
+    moved, _ = _dump(tmp_path, "cornell", 64, 36, ("--no-gpu", "--move-node", "7", "0.25", "0.125", "-0.5"))
+    diff = [i for i in range(len(base["instances"])) if base["instances"][i].tobytes() != moved["instances"][i].tobytes()]
+    assert len(diff) == 1
+    a, b = base["instances"][diff[0]], moved["instances"][diff[0]]
+    assert np.array_equal(b["m_World"][3, :3], a["m_World"][3, :3] + np.array([0.25, 0.125, -0.5], np.float32))
+    assert np.array_equal(b["m_World"][:3], a["m_World"][:3])
+    assert np.array_equal(b["m_Center"], b["m_World"][3, :3])     # UpdateNodeBoundingSphere: the procedural meshes are centred on their origin
+    assert b["m_MaterialIndex"] == a["m_MaterialIndex"] and b["m_MeshDataIndex"] == a["m_MeshDataIndex"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("builder", ["host", "gpu"])
+def test_plugin_path_with_a_moved_node_equals_oracle(tmp_path, luts, builder):
+    """Upload, move a node, render: Renderer::UploadDirtyInstanceTransforms -> hrpt_update_instances rebuilds the tree; the frames equal
+    the oracle's on the moved scene (the dump is written after the move)."""
+    from oracle.binding import Oracle
+    w, h, frames, bounces = 128, 72, 2, 4
+    env = dict(os.environ, HRPT_BVH_BUILDER=builder)
+    prefix = str(tmp_path / "moved")
+    subprocess.check_call([DEMO, "--scene", "cornell", "--width", str(w), "--height", str(h), "--dump", "--out", prefix, "--frames", str(frames),
+                           "--bounces", str(bounces), "--move-node", "7", "0.25", "0.125", "-0.5"], env=env)
+    load = lambda name, dt: np.fromfile(prefix + "_" + name + ".bin", dt)
+    view, misc = load("view", S.PlanarViewConstants)[0], load("misc", np.float32)
+    sc = S.SceneArrays(load("vertices", S.VertexQuantized), load("indices", np.uint32), load("meshdata", S.MeshData), load("instances", S.PerInstanceData),
+                       load("materials", S.MaterialConstants), load("lights", S.GPULight), luts, [None] * 11)
+    sc.sun_direction = misc[:3].copy()
+    sc.sun_angular_size_deg = float(misc[6])
+    acc = load("accumulation", np.float32).reshape(h, w, 4)
+    o = Oracle(sc)
+    oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, misc[3:6], sc, i, bounces, frame_index=i), w, h, frames)
+    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+    o2 = Oracle(scenes.config_cornell(luts, w, h)[0])          # and it is not the unmoved scene's image
+    unmoved, _ = o2.render_accumulated(lambda i: scenes.fill_constants(view, misc[3:6], sc, i, bounces, frame_index=i), w, h, frames)
+    assert not np.array_equal(acc, unmoved)
+
+
 @pytest.mark.gpu
 def test_plugin_path_on_a_gltf_scene_equals_oracle(tmp_path, luts):
     """C++ route end to end: SceneLoader::LoadSceneFile (glTF + textures + cooked-mesh cache) -> Scene -> PathTracerRenderer::Render
