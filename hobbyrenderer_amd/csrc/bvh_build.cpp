@@ -53,7 +53,7 @@ struct Builder {
         if (count <= minLeaf) return make_leaf(first, count);
 
         uint32_t log2c = 0; while ((1u << log2c) < count) ++log2c;
-        bool forceMedian = depth + log2c + 2 >= kTraversalStackDepth;
+        bool forceMedian = depth + log2c + 2 >= kHostBuilderDepthGoal;
 
         int bestAxis = -1; uint32_t bestSplit = 0; float bestCost = 1e30f;
         constexpr int NB = 16;
@@ -202,6 +202,12 @@ inline void unpack_tangent(const HrptVertexQuantized& q, float* t)
 }
 
 } // namespace
+
+void collapse_bvh2_on_host(const std::vector<HostNode>& nodes2, std::vector<HostNode4>& nodes4, uint32_t& maxDepth4)
+{
+    nodes4.clear(); nodes4.reserve(nodes2.size() / 2 + 1); maxDepth4 = 0;
+    collapse4(nodes2, 0, nodes4, 0, maxDepth4);
+}
 
 bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& error)
 {

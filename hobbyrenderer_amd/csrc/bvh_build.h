@@ -69,7 +69,8 @@ struct BuiltBvh {
 };
 
 constexpr uint32_t kMaxLeafTris = 4;
-constexpr uint32_t kTraversalStackDepth = 32;   // the builder guarantees depth < this
+constexpr uint32_t kTraversalStackDepth = 64;   // 2-wide trees: the builders guarantee depth + 2 <= this (private / LDS + overflow stacks of the kernels)
+constexpr uint32_t kHostBuilderDepthGoal = 32;  // the host SAH builder switches to median splits early enough to stay below this
 
 // Validates every index / range of the scene description (false + message); triCount = world triangles over all instances.
 bool validate_scene(const HrptSceneDesc& scene, uint64_t& triCount, std::string& error);
@@ -77,5 +78,8 @@ void build_instance_shade(const HrptSceneDesc& scene, std::vector<HostInstShade>
 bool scene_needs_tangents(const HrptSceneDesc& scene);
 // validate_scene + host build (binned SAH).
 bool build_scene_bvh(const HrptSceneDesc& scene, BuiltBvh& out, std::string& error);
+
+// Area-greedy 4-wide collapse of a 2-wide tree (depth-first node order); experiment hook for GPU-built trees (HRPT_GPU_BVH_HOST_COLLAPSE).
+void collapse_bvh2_on_host(const std::vector<HostNode>& nodes2, std::vector<HostNode4>& nodes4, uint32_t& maxDepth4);
 
 } // namespace hrt

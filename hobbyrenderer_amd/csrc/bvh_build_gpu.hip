@@ -1,6 +1,7 @@
 // bvh_build_gpu.hip -- the acceleration structure of Scene::BuildAccelerationStructures (/root/reference/src/Scene.cpp:67-214)
 // built ON the GPU: world-space triangle setup, 63-bit Morton codes, radix sort (rocPRIM), Karras-2012
-// radix-tree hierarchy, bottom-up bounds, leaf formation (<= 4 triangles), BVH2 emission, 4-wide collapse and the per-triangle
+// radix-tree hierarchy, bottom-up bounds, leaf formation (<= 4 triangles), depth-first node numbering, BVH2 emission, area-greedy
+// 4-wide collapse and the per-triangle
 // shading-attribute records -- the same outputs as the host builder (bvh_build.cpp), in device memory, without the host ever
 // touching a triangle. The reference hands this job to the D3D12 driver (BLAS/TLAS build on the graphics queue); real-time modes
 // rebuild the TLAS every frame (src/CommonRenderers.cpp:234-246), which is what a GPU build is for.
@@ -37,13 +38,15 @@ struct BuildBuffers {
     GpuTri* triU; float4* boxMinU; float4* boxMaxU;
     uint64_t* keyA; uint64_t* keyB; uint32_t* valA; uint32_t* valB;
     uint32_t* sceneBounds;      // 6 ordered-uint floats: centroid min xyz, max xyz
-    uint32_t* flags;            // [0] non-finite vertex seen, [1] max depth of the kept BVH2, [2] kept inner node count (host reads)
+    uint32_t* flags;            // [0] non-finite vertex seen, [1] max depth of the kept BVH2, [2] max depth of the 4-wide tree
     // radix tree (n-1 internal nodes)
     uint32_t* childL; uint32_t* childR; uint32_t* rangeFirst; uint32_t* rangeLast; uint32_t* parentOfInternal; uint32_t* parentOfLeaf;
     uint32_t* visit; float4* nodeMin; float4* nodeMax;
     uint32_t* keep; uint32_t* newIndex;         // kept (range > 4) internal nodes -> dense BVH2 index
     uint32_t* keptParent; uint32_t* depth;      // per dense BVH2 node
-    uint32_t* even; uint32_t* index4;           // per dense BVH2 node: even depth -> BVH4 node index
+    uint32_t* even; uint32_t* index4;           // per dense BVH2 node: root of a 4-wide node (flag) -> BVH4 node index
+    uint32_t* depth4;                           // per dense BVH2 node that roots a 4-wide node: its depth in the 4-wide tree
+    uint32_t* pre; uint32_t* keepPre; uint32_t* densePre;   // depth-first (pre-order) rank of every hierarchy node; keep flags / dense indices in that order
     // PLOC: node pool of 2n entries (0..n-1 leaves in Morton order, n + c = c-th merged node), cluster lists, per-iteration scratch
     float4* pMin; float4* pMax; uint32_t* pSize; uint32_t* pParent; uint32_t* pL; uint32_t* pR;
     uint32_t* clusterA; uint32_t* clusterB; uint32_t* nn; uint32_t* mergeFlag; uint32_t* validFlag; uint32_t* mergeIdx; uint32_t* validIdx;
@@ -301,6 +304,8 @@ __global__ __launch_bounds__(kB) void k_ploc_finish(BuildBuffers b, uint32_t* __
     b.childL[id] = ref(b.pL[v]); b.childR[id] = ref(b.pR[v]);
     b.nodeMin[id] = b.pMin[v]; b.nodeMax[id] = b.pMax[v];
     b.rangeFirst[id] = b.finalPos[v]; b.rangeLast[id] = b.finalPos[v] + b.pSize[v] - 1u;
+    const uint32_t pp = b.pParent[v];
+    b.parentOfInternal[id] = pp == 0xFFFFFFFFu ? 0xFFFFFFFFu : (n - 2u) - (pp - n);
 }
 
 // ---- 5. leaves of up to 4 triangles: an internal node stays inner iff its range holds more than kMaxLeafTris primitives
@@ -309,6 +314,25 @@ __global__ __launch_bounds__(kB) void k_classify(BuildBuffers b, uint32_t maxLea
     uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i + 1 >= b.triCount) return;
     b.keep[i] = (b.rangeLast[i] - b.rangeFirst[i] + 1u > maxLeaf) ? 1u : 0u;
+}
+
+// ---- 5b. depth-first numbering. The dense node index decides where a node lives in memory; the traversal kernels walk the tree depth
+// first, so nodes are numbered in pre-order: rank(v) = (leaves left of v's subtree) - (right turns on the path from the root) + depth(v),
+// since a left sibling subtree with k leaves holds k - 1 inner nodes. The kept nodes (classify) are then compacted IN THAT ORDER.
+__global__ __launch_bounds__(kB) void k_preorder(BuildBuffers b)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i + 1 >= b.triCount) return;
+    uint32_t rightTurns = 0, depth = 0, node = i;
+    for (uint32_t p = b.parentOfInternal[node]; p != 0xFFFFFFFFu; p = b.parentOfInternal[p]) { if (b.childR[p] == node) ++rightTurns; ++depth; node = p; }
+    const uint32_t r = b.rangeFirst[i] - rightTurns + depth;
+    b.pre[i] = r; b.keepPre[r] = b.keep[i];
+}
+__global__ __launch_bounds__(kB) void k_preorder_gather(BuildBuffers b)
+{
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i + 1 >= b.triCount) return;
+    b.newIndex[i] = b.densePre[b.pre[i]];
 }
 
 __device__ __forceinline__ int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1u)); }
@@ -345,14 +369,14 @@ __global__ __launch_bounds__(kB) void k_emit2(BuildBuffers b)
     if (i == 0) b.keptParent[0] = 0xFFFFFFFFu;
 }
 
-// ---- 7. depth of every dense node (walk to the root), max depth, even-depth flags
+// ---- 7. depth of every dense node (walk to the root), max depth
 __global__ __launch_bounds__(kB) void k_depth(BuildBuffers b, uint32_t nodeCount)
 {
     uint32_t k = blockIdx.x * kB + threadIdx.x;
     uint32_t d = 0;
     if (k < nodeCount) {
         for (uint32_t p = b.keptParent[k]; p != 0xFFFFFFFFu; p = b.keptParent[p]) ++d;
-        b.depth[k] = d; b.even[k] = (d & 1u) ? 0u : 1u;
+        b.depth[k] = d;
     }
     uint32_t m = d;
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
@@ -374,31 +398,67 @@ __global__ __launch_bounds__(kB) void k_sah(BuildBuffers b, uint32_t nodeCount, 
     if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(costOut, c);
 }
 
-// ---- 8. 4-wide collapse: every even-depth node absorbs its inner children (two BVH2 levels per BVH4 level)
-__global__ __launch_bounds__(kB) void k_emit4(BuildBuffers b, uint32_t nodeCount)
+// ---- 8. 4-wide collapse, area-greedy like the host builder (bvh_build.cpp collapse4): the children of a 4-wide node start as the two
+// children of its 2-wide root; the inner child with the largest box is replaced by its own two children until four slots are used.
+// Which 2-wide nodes root a 4-wide node depends on the choices above them, so the flags are set top-down, one launch per 2-wide depth
+// (a root at depth d only marks nodes at depths d+1..d+3); 4-wide indices are the prefix sum of the flags in dense = pre-order.
+struct Wide4 { int32_t ref[4]; float mn[4][3], mx[4][3]; int cnt; };
+__device__ __forceinline__ void greedy_children(const GpuNode* __restrict__ nodes, uint32_t k, bool greedy, Wide4& w)
+{
+    auto set = [&](int s, int32_t r, const float* a, const float* c) { w.ref[s] = r; for (int t = 0; t < 3; ++t) { w.mn[s][t] = a[t]; w.mx[s][t] = c[t]; } };
+    GpuNode n = nodes[k];
+    set(0, n.left, n.lmin, n.lmax); set(1, n.right, n.rmin, n.rmax); w.cnt = 2;
+    if (!greedy) {          // two fixed 2-wide levels per 4-wide level: the 4-wide depth is exactly half the 2-wide depth
+        const int32_t l = n.left, r = n.right;
+        if (r >= 0) { GpuNode m = nodes[r]; set(1, m.left, m.lmin, m.lmax); set(2, m.right, m.rmin, m.rmax); w.cnt = 3; }
+        if (l >= 0) { GpuNode m = nodes[l]; set(0, m.left, m.lmin, m.lmax); if (w.cnt == 3) set(3, m.right, m.rmin, m.rmax); else set(2, m.right, m.rmin, m.rmax); ++w.cnt; }
+        return;
+    }
+    while (w.cnt < 4) {
+        int best = -1; float bestArea = -1.0f;
+        for (int i = 0; i < w.cnt; ++i)
+            if (w.ref[i] >= 0) {
+                float dx = w.mx[i][0] - w.mn[i][0], dy = w.mx[i][1] - w.mn[i][1], dz = w.mx[i][2] - w.mn[i][2];
+                float a = dx * dy + dy * dz + dz * dx;
+                if (a > bestArea) { bestArea = a; best = i; }
+            }
+        if (best < 0) break;
+        GpuNode m = nodes[w.ref[best]];
+        // static slot indices only (runtime-indexed private arrays go to scratch): best is 0..2, the new slot is cnt
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (i == best) set(i, m.left, m.lmin, m.lmax);
+#pragma unroll
+        for (int i = 2; i < 4; ++i) if (i == w.cnt) set(i, m.right, m.rmin, m.rmax);
+        ++w.cnt;
+    }
+}
+__global__ void k_mark4_init(BuildBuffers b) { b.even[0] = 1u; b.depth4[0] = 0u; }
+__global__ __launch_bounds__(kB) void k_mark4(BuildBuffers b, uint32_t nodeCount, uint32_t depth, bool greedy)
+{
+    uint32_t k = blockIdx.x * kB + threadIdx.x;
+    uint32_t m = 0;
+    if (k < nodeCount && b.depth[k] == depth && b.even[k]) {
+        Wide4 w; greedy_children(b.nodes, k, greedy, w);
+        const uint32_t d4 = b.depth4[k] + 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < w.cnt && w.ref[i] >= 0) { b.even[w.ref[i]] = 1u; b.depth4[w.ref[i]] = d4; m = d4; }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&b.flags[2], m);
+}
+__global__ __launch_bounds__(kB) void k_emit4(BuildBuffers b, uint32_t nodeCount, bool greedy)
 {
     uint32_t k = blockIdx.x * kB + threadIdx.x;
     if (k >= nodeCount || !b.even[k]) return;
-    int32_t ref[4]; float mn[4][3], mx[4][3]; int cnt = 0;
-    auto push = [&](int32_t r, float4 a, float4 c) { ref[cnt] = r; mn[cnt][0] = a.x; mn[cnt][1] = a.y; mn[cnt][2] = a.z; mx[cnt][0] = c.x; mx[cnt][1] = c.y; mx[cnt][2] = c.z; ++cnt; };
-    auto f4 = [](const float* p) { return make_float4(p[0], p[1], p[2], 0.0f); };
-    GpuNode n = b.nodes[k];
-    int32_t c2[2] = { n.left, n.right };
-    float4 bmn[2] = { f4(n.lmin), f4(n.rmin) }, bmx[2] = { f4(n.lmax), f4(n.rmax) };
-    for (int s = 0; s < 2; ++s) {
-        if (c2[s] >= 0) {
-            GpuNode m = b.nodes[c2[s]];
-            push(m.left, f4(m.lmin), f4(m.lmax));
-            push(m.right, f4(m.rmin), f4(m.rmax));
-        } else push(c2[s], bmn[s], bmx[s]);
-    }
+    Wide4 w; greedy_children(b.nodes, k, greedy, w);
     GpuNode4 o;
     float* px[6] = { &o.minx.x, &o.miny.x, &o.minz.x, &o.maxx.x, &o.maxy.x, &o.maxz.x };
     int32_t* pc = &o.child.x;
+#pragma unroll
     for (int s = 0; s < 4; ++s) {
-        bool used = s < cnt;
-        for (int a = 0; a < 3; ++a) { px[a][s] = used ? mn[s][a] : 1e30f; px[3 + a][s] = used ? mx[s][a] : 1e30f; }   // far degenerate box = never hit
-        pc[s] = used ? (ref[s] >= 0 ? (int32_t)b.index4[ref[s]] : ref[s]) : 0x7fffffff;
+        bool used = s < w.cnt;
+        for (int a = 0; a < 3; ++a) { px[a][s] = used ? w.mn[s][a] : 1e30f; px[3 + a][s] = used ? w.mx[s][a] : 1e30f; }   // far degenerate box = never hit
+        pc[s] = used ? (w.ref[s] >= 0 ? (int32_t)b.index4[w.ref[s]] : w.ref[s]) : 0x7fffffff;
     }
     o.pad = make_uint4(0, 0, 0, 0);
     b.nodes4[b.index4[k]] = o;
@@ -522,7 +582,8 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
         b.parentOfInternal = A.take<uint32_t>(n); b.parentOfLeaf = A.take<uint32_t>(n); b.visit = A.take<uint32_t>(n);
         b.nodeMin = A.take<float4>(n); b.nodeMax = A.take<float4>(n);
         b.keep = A.take<uint32_t>(n); b.newIndex = A.take<uint32_t>(n); b.keptParent = A.take<uint32_t>(n); b.depth = A.take<uint32_t>(n);
-        b.even = A.take<uint32_t>(n); b.index4 = A.take<uint32_t>(n);
+        b.even = A.take<uint32_t>(n); b.index4 = A.take<uint32_t>(n); b.depth4 = A.take<uint32_t>(n);
+        b.pre = A.take<uint32_t>(n); b.keepPre = A.take<uint32_t>(n); b.densePre = A.take<uint32_t>(n);
         b.pMin = A.take<float4>(2 * (size_t)n); b.pMax = A.take<float4>(2 * (size_t)n); b.pSize = A.take<uint32_t>(2 * (size_t)n); b.pParent = A.take<uint32_t>(2 * (size_t)n);
         b.pL = A.take<uint32_t>(2 * (size_t)n); b.pR = A.take<uint32_t>(2 * (size_t)n); b.finalPos = A.take<uint32_t>(2 * (size_t)n);
         b.clusterA = A.take<uint32_t>(n); b.clusterB = A.take<uint32_t>(n); b.nn = A.take<uint32_t>(n); b.mergeFlag = A.take<uint32_t>(n); b.validFlag = A.take<uint32_t>(n);
@@ -614,12 +675,14 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
         }
         (void)hipMemsetAsync(b.flags + 1, 0, 4, stream);
         hipLaunchKernelGGL(k_classify, gT, blk, 0, stream, b, maxLeafTris);
-        if ((e = rocprim::exclusive_scan(prim, scanBytes, b.keep, b.newIndex, 0u, n - 1, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(keep)");
+        hipLaunchKernelGGL(k_preorder, gT, blk, 0, stream, b);
+        if ((e = rocprim::exclusive_scan(prim, scanBytes, b.keepPre, b.densePre, 0u, n - 1, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(keep)");
+        hipLaunchKernelGGL(k_preorder_gather, gT, blk, 0, stream, b);
         hipLaunchKernelGGL(k_emit2, gT, blk, 0, stream, b);
-        // dense node count = newIndex[n-2] + keep[n-2]
+        // dense node count = densePre[n-2] + keepPre[n-2]
         uint32_t tail[2] = { 0, 0 };
-        if ((e = hipMemcpyAsync(&tail[0], b.newIndex + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
-            (e = hipMemcpyAsync(&tail[1], b.keep + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        if ((e = hipMemcpyAsync(&tail[0], b.densePre + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(&tail[1], b.keepPre + (n - 2), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
             (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (hierarchy)");
         nodeCount = tail[0] + tail[1];
         if (nodeCount == 0) return fail(hipErrorUnknown, "GPU BVH build produced no inner node");
@@ -631,8 +694,15 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     }
     m.lastBudget = fitted;
     const dim3 gN((nodeCount + kB - 1) / kB);
+    // Area-greedy collapse (fuller nodes with tighter boxes: it is what makes a PLOC tree as fast as the host's SAH tree); the fixed
+    // two-levels-at-a-time rule stays available for A/B runs (HRPT_GPU_BVH_COLLAPSE=fixed).
+    bool greedy = true;
+    if (const char* e = getenv("HRPT_GPU_BVH_COLLAPSE")) greedy = strcmp(e, "fixed") != 0;
+    (void)hipMemsetAsync(b.even, 0, (size_t)nodeCount * 4, stream);
+    hipLaunchKernelGGL(k_mark4_init, dim3(1), dim3(1), 0, stream, b);
+    for (uint32_t d = 0; d <= maxDepthSeen; ++d) hipLaunchKernelGGL(k_mark4, gN, blk, 0, stream, b, nodeCount, d, greedy);
     if ((e = rocprim::exclusive_scan(prim, scanBytes, b.even, b.index4, 0u, nodeCount, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(even)");
-    hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount);
+    hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount, greedy);
     float* sahDev = reinterpret_cast<float*>(b.flags + 4);
     (void)hipMemsetAsync(sahDev, 0, 4, stream);
     hipLaunchKernelGGL(k_sah, gN, blk, 0, stream, b, nodeCount, sahDev);
@@ -657,7 +727,7 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
         float ra = dx * dy + dy * dz + dz * dx;
         out.sahCost = ra > 0.0f ? 1.0f + sahSum / ra : 0.0f;
     }
-    out.maxDepth = maxDepthSeen; out.maxDepth4 = maxDepthSeen / 2; out.mortonBits = (uint32_t)usedBits; out.ploc = usedPloc; out.deviceMs = ms;
+    out.maxDepth = maxDepthSeen; out.maxDepth4 = flags[2]; out.mortonBits = (uint32_t)usedBits; out.ploc = usedPloc; out.deviceMs = ms;
     return hipSuccess;
 }
 

@@ -203,6 +203,15 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
             v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
             v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
             maxDepth = g.maxDepth; maxDepth4 = g.maxDepth4; built = true;
+            if (getenv("HRPT_GPU_BVH_HOST_COLLAPSE")) {     // experiment: the GPU-built 2-wide tree with the host's area-greedy, depth-first 4-wide collapse
+                std::vector<HostNode> n2(g.nodeCount); std::vector<HostNode4> n4; uint32_t d4 = 0;
+                HIP_TRY(c, hipMemcpy(n2.data(), g.nodes, n2.size() * sizeof(HostNode), hipMemcpyDeviceToHost));
+                collapse_bvh2_on_host(n2, n4, d4);
+                const HostNode4* dn4;
+                if ((r = upload(c, n4.data(), n4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)n4.size(); maxDepth4 = d4;
+            }
             c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits; c->buildInfo.sahCost = g.sahCost;
         } else {
             // too deep for the traversal stacks (or a device error): drop the device-side builder and build on the host instead

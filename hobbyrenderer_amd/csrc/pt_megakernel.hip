@@ -9,9 +9,9 @@
 namespace hrt {
 
 struct PrivateStack {
-    int32_t e[32];
-    HRT_DEV void push(int sp, int32_t v) { e[sp & 31] = v; }
-    HRT_DEV int32_t pop(int sp) { return e[sp & 31]; }
+    int32_t e[64];          // kTraversalStackDepth (bvh_build.h)
+    HRT_DEV void push(int sp, int32_t v) { e[sp & 63] = v; }
+    HRT_DEV int32_t pop(int sp) { return e[sp & 63]; }
 };
 
 HRT_DEV unsigned long long wave_sum(unsigned int v)

@@ -28,6 +28,8 @@ struct SceneTraits {
 struct WavefrontState {
     void* pool = nullptr;              // one device allocation carved into the SoA queues
     size_t poolBytes = 0;
+    void* spill = nullptr;             // traversal-stack overflow columns (only for trees deeper than the LDS stack)
+    size_t spillBytes = 0;
     // start/stop event pairs around every extend / shade / shadow launch; kind[i] = 0,1,2
     std::vector<hipEvent_t> events;
     std::vector<uint8_t> kind;

@@ -62,17 +62,35 @@ struct WfArgs {
     uint32_t hasStochasticAlpha;
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
+    int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
     DeviceCounters* counters;
 };
 
 struct JitterTable { float2 j[kMaxSppPerBatch]; };
 
 // per-lane traversal stack in LDS: element (sp, lane-in-block) at base[sp * kBlock]
-template <int DEPTH>
+// DEPTH 64 = "deeper than 32": the first 32 entries stay in LDS, the (rarely reached) rest lives in a per-lane column of global memory.
+// A 64-entry LDS stack is 64 KB per block, i.e. two blocks per CU: it cost 40 % on the scenes that needed it, although the worst case
+// 3 * depth4 + 2 that forces the size is never approached by real rays.
+// Measured (MI355X): a 64-entry LDS stack -> 32 + spill: -33 % frame time on the 1.17 M-triangle scene; closest-hit kernel 32 -> 16 LDS
+// entries + spill: another -3 % there and on config 4 (occupancy); the shadow kernel is faster with 32 (+4 % with 16 on configs 4, 5).
+constexpr int kExtendLdsStack = 16, kShadowLdsStack = 32;
+constexpr uint32_t kMaxStackNeed = 128;        // deepest supported 4-wide stack need (3 * depth4 + 2)
+template <int DEPTH, int LDSMAX>
 struct LdsStack {
-    int32_t* base;
-    HRT_DEV void push(int sp, int32_t v) { base[(sp & (DEPTH - 1)) * kBlock] = v; }
-    HRT_DEV int32_t pop(int sp) { return base[(sp & (DEPTH - 1)) * kBlock]; }
+    static constexpr int kLdsStackMax = LDSMAX;
+    static constexpr int kLds = DEPTH > kLdsStackMax ? kLdsStackMax : DEPTH;
+    int32_t* base; int32_t* spill; uint32_t spillStride;
+    HRT_DEV void push(int sp, int32_t v)
+    {
+        if (DEPTH <= kLdsStackMax || sp < kLds) base[(sp & (kLds - 1)) * kBlock] = v;
+        else spill[(size_t)(sp - kLds) * spillStride] = v;
+    }
+    HRT_DEV int32_t pop(int sp)
+    {
+        if (DEPTH <= kLdsStackMax || sp < kLds) return base[(sp & (kLds - 1)) * kBlock];
+        return spill[(size_t)(sp - kLds) * spillStride];
+    }
 };
 // per-lane buffer of the K closest non-opaque shadow candidates: (t, triangle) of entry k at base[(k*2 + {0,1}) * kBlock];
 // the barycentrics are recomputed from the triangle when the candidate is processed (same test => same bits)
@@ -101,13 +119,14 @@ template <int W> struct GlobalBvhOf;
 template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV GlobalBvh make(const SceneView& s) { GlobalBvh g; g.nodes = s.nodes; g.tris = s.tris; return g; } };
 template <> struct GlobalBvhOf<4> { using type = GlobalBvh4; static HRT_DEV GlobalBvh4 make(const SceneView& s) { GlobalBvh4 g; g.nodes = s.nodes4; g.tris = s.tris; return g; } };
 
-// Carves dynamic LDS: [stack: DEPTH*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
-template <bool LDS_BVH, int DEPTH, int W>
-HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH>& stack, LdsBvh<W>& lbvh, size_t extraBytes = 0)
+// Carves dynamic LDS: [stack: min(DEPTH, 32)*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
+template <bool LDS_BVH, int DEPTH, int W, int LDSMAX>
+HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH, LDSMAX>& stack, LdsBvh<W>& lbvh, size_t extraBytes = 0)
 {
     stack.base = reinterpret_cast<int32_t*>(smem) + threadIdx.x;
+    stack.spill = nullptr; stack.spillStride = 0;
     if (LDS_BVH) {
-        float4* dst = reinterpret_cast<float4*>(smem + (size_t)DEPTH * kBlock * 4 + extraBytes);
+        float4* dst = reinterpret_cast<float4*>(smem + (size_t)LdsStack<DEPTH, LDSMAX>::kLds * kBlock * 4 + extraBytes);
         const float4* srcN = W == 2 ? reinterpret_cast<const float4*>(s.nodes) : reinterpret_cast<const float4*>(s.nodes4);
         const float4* srcT = reinterpret_cast<const float4*>(s.tris);
         uint32_t nN = W == 2 ? s.nodeCount * 4 : s.node4Count * 8, nT = s.triCount * 3;
@@ -209,8 +228,9 @@ template <bool LDS_BVH, int DEPTH, int W>
 __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStack<DEPTH> stack; LdsBvh<W> lbvh;
+    LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh);
+    if (DEPTH > kExtendLdsStack) { stack.spill = a.spill[0] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
 
@@ -511,10 +531,11 @@ template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, bool NONOPAQUE>
 __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStack<DEPTH> stack; LdsBvh<W> lbvh;
+    LdsStack<DEPTH, kShadowLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = NONOPAQUE ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
-    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)DEPTH * kBlock * 4) + threadIdx.x;
+    if (DEPTH > kShadowLdsStack) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kShadowLdsStack>::kLds * kBlock * 4) + threadIdx.x;
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
@@ -636,7 +657,7 @@ template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStrea
 template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
 {
     if (v.width == 2) {
-        if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity); else launch_extend_t<L, 32, 2>(g, sh, st, a, parity);
+        if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_t<L, 32, 2>(g, sh, st, a, parity); else launch_extend_t<L, 64, 2>(g, sh, st, a, parity);
     } else {
         if (v.depth <= 16) launch_extend_t<L, 16, 4>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_t<L, 32, 4>(g, sh, st, a, parity); else launch_extend_t<L, 64, 4>(g, sh, st, a, parity);
     }
@@ -644,7 +665,7 @@ template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t
 template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
 {
     if (v.width == 2) {
-        if (v.depth <= 8) launch_shadow_t<L, 8, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<L, 16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        if (v.depth <= 8) launch_shadow_t<L, 8, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<L, 16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     } else {
         if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     }
@@ -670,6 +691,8 @@ void wavefront_release(WavefrontState& st)
 {
     if (st.pool) (void)hipFree(st.pool);
     st.pool = nullptr; st.poolBytes = 0;
+    if (st.spill) (void)hipFree(st.spill);
+    st.spill = nullptr; st.spillBytes = 0;
     for (hipEvent_t e : st.events) (void)hipEventDestroy(e);
     st.events.clear(); st.eventsUsed = 0;
     for (hipEvent_t e : st.forkEvents) (void)hipEventDestroy(e);
@@ -774,22 +797,34 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // read the BVH from global memory (-9..-14%); the small opaque any-hit kernel over an LDS-resident BVH is faster 2-wide
     // (the 4-wide step costs it 12 VGPRs = one wave of occupancy).
     const size_t candBytes = traits.hasNonOpaque ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
-    auto pick = [&](int width, size_t extraBytes) {
+    auto pick = [&](int width, size_t extraBytes, int ldsStackMax) {
         Variant v; v.width = width;
-        if (v.width == 4 && 3 * traits.bvh4MaxDepth + 2 > 64) v.width = 2;
-        if (v.width == 2) v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : 32);
+        if (v.width == 4 && 3 * traits.bvh4MaxDepth + 2 > kMaxStackNeed) v.width = 2;
+        if (v.width == 2) v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : (traits.bvhMaxDepth + 2 <= 32 ? 32 : 64));
         else v.depth = 3 * traits.bvh4MaxDepth + 2 <= 16 ? 16 : (3 * traits.bvh4MaxDepth + 2 <= 32 ? 32 : 64);
         const size_t bvhBytes = (v.width == 2 ? (size_t)scene.nodeCount * 64 : (size_t)scene.node4Count * 128) + (size_t)scene.triCount * 48;
-        const size_t stackBytes = (size_t)v.depth * kBlock * 4;
+        const size_t stackBytes = (size_t)(v.depth > ldsStackMax ? ldsStackMax : v.depth) * kBlock * 4;
         v.lds = bvhBytes > 0 && stackBytes + extraBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
         v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0) + st.padLdsBytes;
         return v;
     };
     const int forced = st.bvhWidth == 2 ? 2 : (st.bvhWidth == 4 ? 4 : 0);
-    const Variant vE = pick(forced ? forced : 4, 0);
-    Variant vS = pick(forced ? forced : 4, candBytes);
-    if (!forced && vS.lds && !traits.hasNonOpaque) vS = pick(2, candBytes);
+    const Variant vE = pick(forced ? forced : 4, 0, kExtendLdsStack);
+    Variant vS = pick(forced ? forced : 4, candBytes, kShadowLdsStack);
+    if (!forced && vS.lds && !traits.hasNonOpaque) vS = pick(2, candBytes, kShadowLdsStack);
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)
+    if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
+        // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part
+        const uint32_t worst = vE.width == 4 || vS.width == 4 ? 3 * traits.bvh4MaxDepth + 2 : traits.bvhMaxDepth + 2;
+        const uint32_t entries = worst > (uint32_t)kExtendLdsStack ? worst - kExtendLdsStack : 1u;
+        const size_t threads = (size_t)cus * blocksPerCu * kBlock, bytes = 2 * threads * entries * 4;
+        if (bytes > st.spillBytes) {
+            if (st.spill) { (void)hipStreamSynchronize(stream); if (st.auxStream) (void)hipStreamSynchronize(st.auxStream); (void)hipFree(st.spill); st.spill = nullptr; st.spillBytes = 0; }
+            if ((e = hipMalloc(&st.spill, bytes)) != hipSuccess) { error = "hipMalloc(traversal stack overflow)"; return e; }
+            st.spillBytes = bytes;
+        }
+        a.spill[0] = static_cast<int32_t*>(st.spill); a.spill[1] = a.spill[0] + threads * entries;
+    }
 
     const bool manyLights = maxLights > 1;
     const bool simpleScene = !traits.hasTextures && !traits.hasTransmissiveOrBlend && traits.directionalLightsOnly && !st.forceGeneralShade;
