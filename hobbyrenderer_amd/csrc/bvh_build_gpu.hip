@@ -634,7 +634,7 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     // Hierarchy attempts, best tree first: PLOC (when asked for), then the radix tree over the full 63-bit codes, then radix trees over
     // fewer Morton bits (no re-sort: the order stays the full-code order) until the depth fits the traversal stacks.
     uint32_t nodeCount = 0, maxDepthSeen = 0; int usedBits = 0; bool usedPloc = false;
-    uint32_t maxLeafTris = 4;
+    uint32_t maxLeafTris = 2;          // measured with the greedy collapse: 2 beats 4 on all three test scenes for both hierarchies (-2..-6 % frame time)
     if (const char* e = getenv("HRPT_GPU_BVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) maxLeafTris = (uint32_t)v; }
     const int attempts[] = { 64, 63, 48, 39, 30, 21, 12, 0 };          // 64 = PLOC
     uint32_t* const mortonOrder = b.valB;                              // leaf k of the radix tree = triangle mortonOrder[k]

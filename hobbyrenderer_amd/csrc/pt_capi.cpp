@@ -46,7 +46,7 @@ struct HrptContext {
     bool timed = false;
     WavefrontState wf;
     SceneTraits traits;
-    int bvhBuilder = HRPT_BVH_BUILDER_HOST_SAH;   // hrpt_set_bvh_builder
+    int bvhBuilder = HRPT_BVH_BUILDER_AUTO;       // hrpt_set_bvh_builder
     HrptBuildInfo buildInfo{};
 };
 
@@ -141,7 +141,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
-    if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "ploc") == 0 || strcmp(e, "2") == 0) ? HRPT_BVH_BUILDER_GPU_PLOC : ((strcmp(e, "gpu") == 0 || strcmp(e, "lbvh") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : HRPT_BVH_BUILDER_HOST_SAH);
+    if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "ploc") == 0 || strcmp(e, "2") == 0) ? HRPT_BVH_BUILDER_GPU_PLOC : ((strcmp(e, "gpu") == 0 || strcmp(e, "lbvh") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : ((strcmp(e, "auto") == 0 || strcmp(e, "3") == 0) ? HRPT_BVH_BUILDER_AUTO : HRPT_BVH_BUILDER_HOST_SAH));
     if (const char* e = getenv("HRPT_WF_PAD_LDS")) c->wf.padLdsBytes = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_DRAIN_SEGMENTS")) c->wf.drainSegments = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
@@ -190,7 +190,9 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
     free_acceleration(c, !firstBuild);
     uint32_t maxDepth = 0, maxDepth4 = 0;
     bool built = false;
-    if ((c->bvhBuilder == HRPT_BVH_BUILDER_GPU_LBVH || c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC) && sceneTris >= 8) {
+    const int builder = c->bvhBuilder == HRPT_BVH_BUILDER_AUTO ? (sceneTris >= 65536 ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_HOST_SAH) : c->bvhBuilder;
+    if (builder != HRPT_BVH_BUILDER_GPU_LBVH && builder != HRPT_BVH_BUILDER_GPU_PLOC) { delete c->gpuBuilder; c->gpuBuilder = nullptr; }
+    if ((builder == HRPT_BVH_BUILDER_GPU_LBVH || builder == HRPT_BVH_BUILDER_GPU_PLOC) && sceneTris >= 8) {
         // the whole build runs on the device; only the per-instance adjugate rows (O(instances)) are prepared on the host
         GpuBuiltBvh g; std::string gerr;
         hipError_t ge = hipSuccess;
@@ -198,7 +200,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
             c->gpuBuilder = new GpuBvhBuilder();
             ge = c->gpuBuilder->prepare(s, scene_needs_tangents(s), c->stream, gerr);
         }
-        if (ge == hipSuccess) ge = c->gpuBuilder->build(s.instances, c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, c->stream, g, gerr);
+        if (ge == hipSuccess) ge = c->gpuBuilder->build(s.instances, builder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, c->stream, g, gerr);
         if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
             v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
             v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
@@ -590,7 +592,7 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
 int hrpt_set_bvh_builder(HrptContext* c, int builder)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
-    if (builder != HRPT_BVH_BUILDER_HOST_SAH && builder != HRPT_BVH_BUILDER_GPU_LBVH && builder != HRPT_BVH_BUILDER_GPU_PLOC) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_bvh_builder: unknown builder");
+    if (builder != HRPT_BVH_BUILDER_HOST_SAH && builder != HRPT_BVH_BUILDER_GPU_LBVH && builder != HRPT_BVH_BUILDER_GPU_PLOC && builder != HRPT_BVH_BUILDER_AUTO) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_bvh_builder: unknown builder");
     c->bvhBuilder = builder;
     return HRPT_OK;
 }

@@ -180,7 +180,7 @@ class PathTracerContext:
         return hits
 
     def set_bvh_builder(self, builder):
-        """S.BVH_BUILDER_HOST_SAH (default) or S.BVH_BUILDER_GPU_LBVH; used by the next upload_scene."""
+        """S.BVH_BUILDER_AUTO (default: host SAH below 65 536 triangles, GPU PLOC above), _HOST_SAH, _GPU_LBVH or _GPU_PLOC; used by the next upload_scene / update_instances."""
         self._check(lib.hrpt_set_bvh_builder(self._h, int(builder)))
 
     def update_instances(self, instances, first=0):

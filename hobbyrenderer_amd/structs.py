@@ -105,7 +105,7 @@ class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
                 ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("pad", C.c_uint32 * 1)]
 
 
-BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC = 0, 1, 2
+BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC, BVH_BUILDER_AUTO = 0, 1, 2, 3
 
 
 def default_material():

@@ -263,14 +263,17 @@ int  hrpt_set_stream(HrptContext* ctx, void* hipStream, int useCallerStream);
 int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output);
 /* ---- acceleration-structure builder --------------------------------------------------------------
  * Scene::BuildAccelerationStructures (src/Scene.cpp:67-214) is a driver BLAS/TLAS build in the reference. Here
- * hrpt_upload_scene builds the library's own structure either on the host (binned SAH, the default: best traversal
- * speed, seconds for millions of triangles) or on the GPU (Morton-order LBVH: milliseconds, for large or frequently
- * rebuilt scenes). Radiance is identical either way (the hit definition is BVH-independent). The GPU builder falls back
- * to the host one for scenes under 8 triangles or when its tree is deeper than the traversal stacks allow. */
+ * hrpt_upload_scene builds the library's own structure either on the host (binned SAH: the best tree, ~0.5 s per million
+ * triangles) or on the GPU (Morton-order LBVH or PLOC clustering: milliseconds). Radiance is identical either way (the hit
+ * definition is BVH-independent). The GPU builders fall back to the host one for scenes under 8 triangles or when their
+ * tree is deeper than the traversal stacks allow. The default, HRPT_BVH_BUILDER_AUTO, takes the host builder below 65 536
+ * triangles and PLOC above (measured on MI355X: same frame time as the SAH tree at 101 k and 1.17 M triangles, 3 ms / 6 ms
+ * instead of 32 ms / 548 ms of build time; on small scenes the SAH tree still renders up to 20 % faster). */
 #define HRPT_BVH_BUILDER_HOST_SAH 0
 #define HRPT_BVH_BUILDER_GPU_LBVH 1      /* Morton radix tree (Karras 2012): fastest build */
 #define HRPT_BVH_BUILDER_GPU_PLOC 2      /* Morton order + nearest-neighbour clustering (PLOC): better tree, a few times the LBVH build time;
                                             falls back to the LBVH hierarchy when its tree is too deep for the traversal stacks */
+#define HRPT_BVH_BUILDER_AUTO     3      /* default: HOST_SAH below 65 536 triangles, GPU_PLOC from there on */
 int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene / hrpt_update_instances */
 typedef struct HrptBuildInfo {
     uint32_t requestedBuilder, usedBuilder;     /* HRPT_BVH_BUILDER_* */

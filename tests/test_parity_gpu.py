@@ -205,6 +205,26 @@ def test_gpu_bvh_builder_parity(luts, flags, builder):
     _assert_parity(*res)
 
 
+def test_default_builder_is_chosen_by_scene_size(luts):
+    """HRPT_BVH_BUILDER_AUTO: host SAH below 65 536 triangles, GPU PLOC (or its LBVH fallback) above; requestedBuilder reports AUTO."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    c = PathTracerContext(0)
+    try:
+        sc, view, pos, cfg = scenes.config_cornell(luts, 64, 36)
+        c.upload_scene(sc)
+        bi = c.build_info()
+        assert bi.requestedBuilder == S.BVH_BUILDER_AUTO and bi.usedBuilder == S.BVH_BUILDER_HOST_SAH
+        sc, view, pos, cfg = scenes.config_sponza_class(luts, 64, 36, detail=1.0, tex_size=32)
+        _assert_parity(*_run_both(c, sc, view, pos, 64, 36, 1, 3, S.FRAME_DEFAULT))
+        bi = c.build_info()
+        assert bi.requestedBuilder == S.BVH_BUILDER_AUTO and bi.usedBuilder in (S.BVH_BUILDER_GPU_PLOC, S.BVH_BUILDER_GPU_LBVH) and bi.triangleCount > 65536
+        c.set_bvh_builder(S.BVH_BUILDER_HOST_SAH)
+        c.upload_scene(sc)
+        assert c.build_info().usedBuilder == S.BVH_BUILDER_HOST_SAH
+    finally:
+        c.close()
+
+
 def test_gpu_bvh_builder_small_and_degenerate(luts):
     from hobbyrenderer_amd.native import PathTracerContext
     c = PathTracerContext(0)
@@ -275,10 +295,11 @@ def test_unaligned_tiles_and_spp_batches(ctx, luts):
 
 @pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
 def test_million_triangle_bvh(ctx, luts, flags):
-    """~1.1 M world triangles (deep BVH, 32-entry LDS stack, BVH streamed from HBM/L2)."""
+    """~1.1 M world triangles: default (AUTO -> GPU PLOC) builder, deep tree (2-wide depth > 32: private 64-entry stack in the megakernel,
+    16 / 32 LDS entries + overflow columns in the wavefront kernels), BVH streamed from HBM/L2."""
     sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=3.4, tex_size=32)
     res = _run_both(ctx, sc, view, pos, 96, 54, 1, 6, flags)
-    assert res[2].bvhTriangleCount > 1000000 and res[2].bvhMaxDepth < 32
+    assert res[2].bvhTriangleCount > 1000000 and res[2].bvhMaxDepth + 2 <= 64
     _assert_parity(*res)
 
 
