@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal only: all ranks share GPU 0 and the all-gather runs over gloo through host memory; the printed value is NOT a result")
     ap.add_argument("--serial-gather", action="store_true", help="N>1: all-gather in stream order after each render instead of overlapping it with the next frame")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
+                    help="independent steps (frames) in flight on each GPU: 2 = consecutive steps alternate between two path-tracer contexts "
+                         "(own streams, queues and images) so that one frame's kernel tails overlap the other's; 1 = one frame at a time")
     ap.add_argument("--force-sharded", action="store_true", help="testing: run the N>1 code path (RCCL all-gather, comm stream) with a single rank")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json config: 2 = headline (Cornell-class), 4 = Sponza-class stand-in, 5 = glass stress stand-in")
@@ -119,6 +122,12 @@ def main():
     ctx = native.PathTracerContext(local_rank)
     ctx.upload_scene(sc)
     ctx.resize(W, H)
+    lanes = [ctx]
+    if args.frames_in_flight == 2 and not rehearse:
+        ctx2 = native.PathTracerContext(local_rank)
+        ctx2.upload_scene(sc)
+        ctx2.resize(W, H)
+        lanes.append(ctx2)
     cb = scenes.fill_constants(view, pos, sc, 0, bounces)
     flags = {"default": S.FRAME_DEFAULT, "megakernel": S.FRAME_MEGAKERNEL, "wavefront": S.FRAME_WAVEFRONT}[args.mode]
 
@@ -139,24 +148,39 @@ def main():
 
     same_stream = sharded and not rehearse
     pipelined = same_stream and not args.serial_gather
+    if not pipelined and sharded:
+        lanes = lanes[:1]
+    lane_streams = None
     if same_stream:
-        # render, band clone, RCCL all-gather and resolve are all ordered on torch's current stream: no host sync in a step
-        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        # render, band clone, RCCL all-gather and resolve are all ordered on torch streams: no host sync in a step
+        if pipelined and len(lanes) == 2:
+            lane_streams = [torch.cuda.Stream(dev) for _ in lanes]
+            for c, st_ in zip(lanes, lane_streams):
+                c.set_stream(st_.cuda_stream)
+        else:
+            ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
-    def render_band(b0, b1):
-        ctx.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags)
-        if not same_stream:
-            ctx.synchronize()                                   # library stream -> host before the host-staged gather
+    def band_renderer(c):
+        def render_band(b0, b1):
+            c.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags)
+            if not same_stream:
+                c.synchronize()                                 # library stream -> host before the host-staged gather
+        return render_band
+    render_band = band_renderer(ctx)
 
     frames = None
     if pipelined:
         # frame k's all-gather + resolve run on a second stream while frame k+1 renders (hobbyrenderer_amd/distributed.py)
-        frames = PipelinedFrames(render_band, full[y0:y1], H, W, rank, world, all_gather,
-                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), H * W, stream), dev)
+        views = [device_tensor(c.device_images()[0], (H, W, 4), dev)[y0:y1] for c in lanes]
+        frames = PipelinedFrames([band_renderer(c) for c in lanes], views, H, W, rank, world, all_gather,
+                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), H * W, stream), dev,
+                                 lane_streams=lane_streams)
+    step_no = [0]
 
     def step():
         if not sharded:
-            ctx.render(cb, accum_count=spp, flags=flags)
+            lanes[step_no[0] % len(lanes)].render(cb, accum_count=spp, flags=flags)   # step k on lane k % L: L frames in flight
+            step_no[0] += 1
         elif pipelined:
             frames.submit()
         else:
@@ -168,7 +192,8 @@ def main():
     def sync_all():
         if frames is not None:
             frames.finish()
-        ctx.synchronize()
+        for c in lanes:
+            c.synchronize()
         torch.cuda.synchronize(dev)
         if sharded:
             dist.barrier()
@@ -177,14 +202,21 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    ctx.reset_stats()
-    ctx.synchronize()
+    for c in lanes:
+        c.reset_stats()
+        c.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    st = ctx.stats()
+
+    class _Sum:                                               # ray counters of all lanes of this rank
+        closestRays = sum(int(c.stats().closestRays) for c in lanes)
+        shadowRays = sum(int(c.stats().shadowRays) for c in lanes)
+    st = _Sum
+    if lane_streams is not None:
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     # per-kernel-class device times: a few extra steps with HRPT_FRAME_PROFILE (events around every launch), outside the timed region
     prof_steps = 0
     if args.mode != "megakernel":
@@ -214,6 +246,7 @@ def main():
             "dtype": "f32", "data": "synthetic" if not rehearse else "REHEARSAL on one GPU (gloo through host): not a result",
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
                        "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
+                       "frames_in_flight": len(lanes),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
         }

@@ -48,25 +48,38 @@ def device_tensor(ptr, shape, device):
 
 
 class PipelinedFrames:
-    """Sharded frames with the all-gather of frame k overlapped with the render of frame k+1.
+    """Sharded frames with the all-gather of frame k overlapped with the render of frame k+1, and (optionally) two frames in flight.
 
-    Per rank: the path-tracer context renders its row band into the context's accumulation image on the compute stream;
+    Per rank: a path-tracer context renders its row band into the context's accumulation image on a compute stream;
     the band is copied (device to device, 16 B/pixel) into one of two staging buffers; a second stream (`comm`) waits for
     that copy, runs the single RCCL all-gather into one of two full-size `gathered` images and resolves Output = rgb / a
-    (hrpt_resolve_device) into the matching `output` image. The compute stream only waits for the comm stream when it is
+    (hrpt_resolve_device) into the matching `output` image. A compute stream only waits for the comm stream when it is
     about to reuse a staging/gathered pair (two frames later), so a frame's xGMI traffic hides behind the next render.
-    finish() joins both streams. On CPU (gloo tests) the same bookkeeping runs without streams.
+    finish() joins all streams. On CPU (gloo tests) the same bookkeeping runs without streams.
 
-    render_band(y0, y1): enqueues the band render on the CURRENT torch stream (the context must be bound to it with
-                         hrpt_set_stream) and returns nothing.
+    Lanes: `render_band` / `band_view` may be lists of L entries (one path-tracer context each) with `lane_streams` the L torch
+    streams those contexts are bound to (hrpt_set_stream). Frame k is rendered by lane k % L, so L consecutive frames are in flight
+    on the GPU at once: a band is too little work to fill 256 CUs through the tail of every kernel (135 rows of config 2:
+    0.74 ms per frame with one lane, 0.62 ms with two, scripts/two_lane_band_probe.py). The gathers stay in frame order on the
+    one comm stream (collectives must be issued in the same order on every rank).
+
+    render_band(y0, y1): enqueues the band render on the lane's stream (the CURRENT torch stream when no lane_streams are given;
+                         the context must be bound to it with hrpt_set_stream) and returns nothing.
     band_view: torch view of rows [y0, y1) of the context's accumulation image.
     resolve(accum_tensor, out_tensor, stream_handle): Output = rgb / a (hrpt_resolve_device on GPUs).
     """
 
-    def __init__(self, render_band, band_view, height, width, rank, world, all_gather, resolve, device):
+    def __init__(self, render_band, band_view, height, width, rank, world, all_gather, resolve, device, lane_streams=None):
         import torch
         self.torch = torch
-        self.render_band, self.band_view, self.all_gather, self.resolve = render_band, band_view, all_gather, resolve
+        self.render_band = list(render_band) if isinstance(render_band, (list, tuple)) else [render_band]
+        self.band_view = list(band_view) if isinstance(band_view, (list, tuple)) else [band_view]
+        if len(self.render_band) != len(self.band_view) or not 1 <= len(self.render_band) <= 2:
+            raise ValueError("one or two lanes, each with a render_band and a band_view")
+        self.lane_streams = list(lane_streams) if lane_streams is not None else None
+        if self.lane_streams is not None and len(self.lane_streams) != len(self.render_band):
+            raise ValueError("one stream per lane")
+        self.all_gather, self.resolve = all_gather, resolve
         self.rank, self.world = rank, world
         self.y0, self.y1 = band_for_rank(height, world, rank)
         self.gpu = device.type == "cuda"
@@ -84,27 +97,32 @@ class PipelinedFrames:
         """Enqueue one frame; returns the slot (0/1) whose `gathered`/`output` images will hold it."""
         torch = self.torch
         s = self.frame & 1
+        lane = self.frame % len(self.render_band)
         if self.gpu:
-            main = torch.cuda.current_stream()
-            if self.frame >= 2:
-                main.wait_event(self.delivered[s])          # slot s is free again once frame-2's gather + resolve are done
-            self.render_band(self.y0, self.y1)
-            self.staging[s].copy_(self.band_view)           # the only payload that crosses xGMI
-            self.rendered[s].record(main)
+            main = self.lane_streams[lane] if self.lane_streams is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(main):
+                if self.frame >= 2:
+                    main.wait_event(self.delivered[s])      # slot s is free again once frame-2's gather + resolve are done
+                self.render_band[lane](self.y0, self.y1)
+                self.staging[s].copy_(self.band_view[lane])  # the only payload that crosses xGMI
+                self.rendered[s].record(main)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.rendered[s])
                 self.all_gather(self.gathered[s], self.staging[s])
                 self.resolve(self.gathered[s], self.output[s], self.comm.cuda_stream)
                 self.delivered[s].record(self.comm)
         else:
-            self.render_band(self.y0, self.y1)
-            self.staging[s].copy_(self.band_view)
+            self.render_band[lane](self.y0, self.y1)
+            self.staging[s].copy_(self.band_view[lane])
             self.all_gather(self.gathered[s], self.staging[s])
             self.resolve(self.gathered[s], self.output[s], 0)
         self.frame += 1
         return s
 
     def finish(self):
-        """Make the compute stream wait for every submitted frame (host synchronisation stays with the caller)."""
+        """Make the current stream wait for every submitted frame (host synchronisation stays with the caller)."""
         if self.gpu:
-            self.torch.cuda.current_stream().wait_stream(self.comm)
+            cur = self.torch.cuda.current_stream()
+            cur.wait_stream(self.comm)
+            for st in self.lane_streams or []:
+                cur.wait_stream(st)

@@ -5,7 +5,7 @@ rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 i=0
 for CTRS in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d gpurun_out/pmc/p$i -- python3 bench.py ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d gpurun_out/pmc/p$i -- python3 bench.py ${BENCH_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 > gpurun_out/pmc/p$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, re

@@ -53,7 +53,7 @@ def test_two_rank_band_sharding_matches_single_rank(tmp_path, luts):
     assert np.array_equal(a1.view(np.uint32), ref.view(np.uint32))
 
 
-def _pipelined_worker(rank, world, port, w, h, bounces, out_dir):
+def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -65,20 +65,23 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir):
     luts = native.precompute_atmosphere(2)
     sc, view, pos, _ = scenes.config_cornell(luts, w, h)
     o = Oracle(sc)
-    acc = np.zeros((h, w, 4), np.float32)
+    accs = [np.zeros((h, w, 4), np.float32) for _ in range(lanes)]      # one accumulation image per lane (= per path-tracer context)
     out = np.zeros((h, w, 4), np.float32)
     state = {"first": 0}
 
-    def render_band(y0, y1):       # frame f = accumulation index f alone, restarted from zero (three different frames)
-        acc[y0:y1] = 0.0
-        o.render(scenes.fill_constants(view, pos, sc, state["first"], bounces), acc, out, (0, y0, w, y1), nthreads=2)
+    def band_renderer(acc):
+        def render_band(y0, y1):   # frame f = accumulation index f alone, restarted from zero (three different frames)
+            acc[y0:y1] = 0.0
+            o.render(scenes.fill_constants(view, pos, sc, state["first"], bounces), acc, out, (0, y0, w, y1), nthreads=2)
+        return render_band
 
     def resolve(a, b, stream):
         b.copy_(a / a[..., 3:4])
 
     y0, y1 = band_for_rank(h, world, rank)
-    full = torch.from_numpy(acc)
-    frames = PipelinedFrames(render_band, full[y0:y1], h, w, rank, world, lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"))
+    fulls = [torch.from_numpy(a) for a in accs]
+    frames = PipelinedFrames([band_renderer(a) for a in accs], [f[y0:y1] for f in fulls], h, w, rank, world,
+                             lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"))
     for f in range(3):
         state["first"] = f
         slot = frames.submit()
@@ -89,14 +92,15 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_pipelined_frames(tmp_path, luts):
-    """PipelinedFrames bookkeeping (double-buffered staging / gathered images) under gloo, world 2: every frame of every
-    rank equals the single-rank image of that accumulation index."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_two_rank_pipelined_frames(tmp_path, luts, lanes):
+    """PipelinedFrames bookkeeping (double-buffered staging / gathered images; one or two lanes = contexts alternating frame by
+    frame) under gloo, world 2: every frame of every rank equals the single-rank image of that accumulation index."""
     from hobbyrenderer_amd import scenes
     from oracle.binding import Oracle
     w, h, bounces = 48, 28, 3
     port = 30100 + (os.getpid() % 500)
-    mp.spawn(_pipelined_worker, args=(2, port, w, h, bounces, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_pipelined_worker, args=(2, port + lanes, w, h, bounces, str(tmp_path), lanes), nprocs=2, join=True)
     sc, view, pos, _ = scenes.config_cornell(luts, w, h)
     o = Oracle(sc)
     for f in range(3):

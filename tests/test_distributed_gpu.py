@@ -73,6 +73,37 @@ def test_device_tensor_view_and_rccl_allgather(luts):
             ref_ctx.close()
             assert np.array_equal(frames.gathered[slot].cpu().numpy().view(np.uint32), ra.view(np.uint32)), f
             assert np.array_equal(frames.output[slot].cpu().numpy().view(np.uint32), ro.view(np.uint32)), f
+        # two lanes: frame k rendered by context k % 2 on its own stream (two frames in flight), gathers in frame order on the comm stream
+        ctx2 = PathTracerContext(0)
+        ctx2.upload_scene(sc); ctx2.resize(128, 72)
+        lanes = [ctx, ctx2]
+        streams = [torch.cuda.Stream(dev) for _ in lanes]
+        for c, st in zip(lanes, streams):
+            c.set_stream(st.cuda_stream)
+        count = {"n": 1}
+
+        def lane_render(c):
+            return lambda a, b: c.render(scenes.fill_constants(view, pos, sc, 0, 4), accum_count=count["n"], tile=(0, a, 128, b))
+        views = [device_tensor(c.device_images()[0], (72, 128, 4), dev)[0:72] for c in lanes]
+        frames = PipelinedFrames([lane_render(c) for c in lanes], views, 72, 128, 0, 1, lambda f, b: dist.all_gather_into_tensor(f, b),
+                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), 72 * 128, stream), dev, lane_streams=streams)
+        got = []
+        for f in range(6):
+            count["n"] = f + 1                       # frame f = accumulation indices 0..f from scratch: every frame differs
+            slot = frames.submit()
+            if f >= 4:
+                got.append((f, slot))
+        frames.finish()
+        torch.cuda.synchronize(dev)
+        for f, slot in got:
+            ref_ctx = PathTracerContext(0)
+            ref_ctx.upload_scene(sc); ref_ctx.resize(128, 72)
+            ref_ctx.render(scenes.fill_constants(view, pos, sc, 0, 4), accum_count=f + 1)
+            ra, ro = ref_ctx.read_accumulation(), ref_ctx.read_output()
+            ref_ctx.close()
+            assert np.array_equal(frames.gathered[slot].cpu().numpy().view(np.uint32), ra.view(np.uint32)), f
+            assert np.array_equal(frames.output[slot].cpu().numpy().view(np.uint32), ro.view(np.uint32)), f
+        ctx2.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
