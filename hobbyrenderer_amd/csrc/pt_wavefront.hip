@@ -337,8 +337,10 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 
 // SIMPLE: scene traits proven at upload -- no textures, no transmissive / BLEND material, directional lights only --
 // compile the corresponding branches out (the general variant is always correct).
+// Occupancy: the multi-light variant is forced to 4 waves per SIMD (28 B of scratch per lane; -9 % on the glass config); the single-light
+// variants stay at 3 (forcing 4 costs them +3 %: 44..108 B of spills on a kernel that is already latency-bound).
 template <int MAXL, bool SIMPLE>
-__global__ __launch_bounds__(kBlock) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1 ? 4 : 3, MAXL > 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
