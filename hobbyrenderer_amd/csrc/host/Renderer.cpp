@@ -46,9 +46,25 @@ int Renderer::UploadDirtyInstanceTransforms()
     return hrpt_update_instances(m_RHI->m_Context, reinterpret_cast<const HrptPerInstanceData*>(m_Scene.m_InstanceData.data() + startIdx), startIdx, count);
 }
 
+int Renderer::UploadDirtyMaterialConstants()
+{
+    if (m_Scene.m_Materials.empty() || m_Scene.m_MaterialDirtyRange.first > m_Scene.m_MaterialDirtyRange.second) return HRPT_OK;
+    const uint32_t firstMat = m_Scene.m_MaterialDirtyRange.first, count = m_Scene.m_MaterialDirtyRange.second - firstMat + 1;
+    m_Scene.m_MaterialDirtyRange = { UINT32_MAX, 0 };
+    if ((size_t)firstMat + count > m_Scene.m_Materials.size()) return HRPT_ERR_INVALID_ARGUMENT;     // the reference asserts (:996-1000)
+    m_Scene.UpdateMaterialsAndCreateConstants();             // MaterialConstantsFromMaterial; the library gets only the dirty range
+    return hrpt_update_materials(m_RHI->m_Context, reinterpret_cast<const HrptMaterialConstants*>(m_Scene.m_MaterialConstants.data() + firstMat), firstMat, count);
+}
+
 int Renderer::RunPathTracerFrame()
 {
     if (int r = UploadDirtyInstanceTransforms()) { m_LastStatus = r; return r; }   // before the renderers run, src/Renderer.cpp:497-498
+    if (m_Scene.m_LightsDirty) {                                                    // :500-504
+        m_Scene.CreateAndUploadLightBuffer();
+        m_Scene.m_LightsDirty = false;
+        if (int r = hrpt_update_lights(m_RHI->m_Context, reinterpret_cast<const HrptGPULight*>(m_Scene.m_GPULights.data()), (uint32_t)m_Scene.m_GPULights.size())) { m_LastStatus = r; return r; }
+    }
+    if (int r = UploadDirtyMaterialConstants()) { m_LastStatus = r; return r; }     // :507
     m_Scene.m_ViewPrev = m_Scene.m_View;
     m_Scene.m_Camera.FillPlanarViewConstants(m_Scene.m_View, (float)m_RHI->m_SwapchainExtent.x, (float)m_RHI->m_SwapchainExtent.y);
     if (m_FrameNumber == 0) m_Scene.m_ViewPrev = srrhi::PlanarViewConstants{};

@@ -33,7 +33,8 @@ struct HrptContext {
     GpuBvhBuilder* gpuBuilder = nullptr;     // GPU builders: geometry + build buffers stay on the device for rebuilds
     // host copy of what a rebuild needs (the reference's Scene keeps the same vectors: m_InstanceData, m_Vertices, m_Indices, m_MeshData)
     std::vector<HrptVertexQuantized> keptVertices; std::vector<uint32_t> keptIndices; std::vector<HrptMeshData> keptMeshData;
-    std::vector<HrptPerInstanceData> keptInstances; std::vector<HrptMaterialConstants> keptMaterials;
+    std::vector<HrptPerInstanceData> keptInstances; std::vector<HrptMaterialConstants> keptMaterials; std::vector<HrptGPULight> keptLights;
+    size_t lightCapacity = 0;                // entries the device light buffer can hold (hrpt_update_lights may grow it)
     SceneView view{};
     bool haveScene = false;
     uint32_t bvhNodes = 0, bvhTris = 0;
@@ -97,7 +98,7 @@ static void free_scene(HrptContext* c)
     free_acceleration(c, false);
     for (void* p : c->allocations) (void)hipFree(p);
     c->allocations.clear();
-    c->keptVertices.clear(); c->keptIndices.clear(); c->keptMeshData.clear(); c->keptInstances.clear(); c->keptMaterials.clear();
+    c->keptVertices.clear(); c->keptIndices.clear(); c->keptMeshData.clear(); c->keptInstances.clear(); c->keptMaterials.clear(); c->keptLights.clear(); c->lightCapacity = 0;
     c->haveScene = false;
     memset(&c->view, 0, sizeof c->view);
 }
@@ -265,6 +266,22 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
     return HRPT_OK;
 }
 
+// What the kernels specialise on (SceneTraits), from the library's copy of instances / materials / lights; the tree depths are kept.
+static void refresh_traits(HrptContext* c)
+{
+    SceneTraits t; t.bvhMaxDepth = c->traits.bvhMaxDepth; t.bvh4MaxDepth = c->traits.bvh4MaxDepth;
+    for (const HrptPerInstanceData& in : c->keptInstances) {
+        const HrptMaterialConstants& m = c->keptMaterials[in.m_MaterialIndex];
+        if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) t.hasMedium = true;
+        if (m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND && !(m.m_TransmissionFactor > 0.0f)) t.hasStochasticAlpha = true;
+        if (m.m_TextureFlags != 0) t.hasTextures = true;
+        if (m.m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) t.hasNonOpaque = true;
+        if (m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) t.hasTransmissiveOrBlend = true;
+    }
+    for (const HrptGPULight& l : c->keptLights) if (l.m_Type != HRPT_LIGHT_DIRECTIONAL) t.directionalLightsOnly = false;
+    c->traits = t;
+}
+
 static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
@@ -283,7 +300,7 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     if ((r = build_acceleration(c, *s, sceneTris, v, true)) != HRPT_OK) return r;
     if ((r = upload(c, s->materials, s->materialCount, &v.materials)) != HRPT_OK) return r;
     if ((r = upload(c, s->lights, s->lightCount, &v.lights)) != HRPT_OK) return r;
-    v.lightCount = s->lightCount;
+    v.lightCount = s->lightCount; c->lightCapacity = s->lightCount;
 
     std::vector<GpuTexture> table(s->textureCount);
     for (uint32_t i = 0; i < s->textureCount; ++i) {
@@ -311,15 +328,80 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     c->keptVertices.assign(s->vertices, s->vertices + s->vertexCount); c->keptIndices.assign(s->indices, s->indices + s->indexCount);
     c->keptMeshData.assign(s->meshData, s->meshData + s->meshDataCount); c->keptInstances.assign(s->instances, s->instances + s->instanceCount);
     c->keptMaterials.assign(s->materials, s->materials + s->materialCount);
-    for (uint32_t i = 0; i < s->instanceCount; ++i) {
-        const HrptMaterialConstants& m = s->materials[s->instances[i].m_MaterialIndex];
-        if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) c->traits.hasMedium = true;
-        if (m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND && !(m.m_TransmissionFactor > 0.0f)) c->traits.hasStochasticAlpha = true;
-        if (m.m_TextureFlags != 0) c->traits.hasTextures = true;
-        if (m.m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) c->traits.hasNonOpaque = true;
-        if (m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) c->traits.hasTransmissiveOrBlend = true;
+    c->keptLights.assign(s->lights, s->lights + s->lightCount);
+    refresh_traits(c);
+    return HRPT_OK;
+}
+
+// The scene description the rebuild paths hand to the builders, over the library's copies.
+static HrptSceneDesc kept_scene_desc(HrptContext* c)
+{
+    HrptSceneDesc s{};
+    s.vertices = c->keptVertices.data(); s.vertexCount = (uint32_t)c->keptVertices.size();
+    s.indices = c->keptIndices.data(); s.indexCount = (uint32_t)c->keptIndices.size();
+    s.meshData = c->keptMeshData.data(); s.meshDataCount = (uint32_t)c->keptMeshData.size();
+    s.instances = c->keptInstances.data(); s.instanceCount = (uint32_t)c->keptInstances.size();
+    s.materials = c->keptMaterials.data(); s.materialCount = (uint32_t)c->keptMaterials.size();
+    static const HrptGPULight noLight{};                 // lights play no part in the build; validate_scene only wants the array to exist
+    s.lights = &noLight; s.lightCount = 1;
+    return s;
+}
+static uint64_t kept_triangle_count(const HrptContext* c)
+{
+    uint64_t n = 0;
+    for (const HrptPerInstanceData& in : c->keptInstances) n += c->keptMeshData[in.m_MeshDataIndex].m_IndexCounts[0] / 3;
+    return n;
+}
+
+static int update_lights_impl(HrptContext* c, const HrptGPULight* lights, uint32_t count)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_lights: no scene uploaded");
+    if (!lights || count == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_lights: a scene needs at least one light (the reference guarantees a directional light, src/Scene.cpp:635-666)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));        // frames in flight still read the old buffer
+    if (count > c->lightCapacity) {
+        const HrptGPULight* d; int r;
+        if ((r = upload(c, lights, count, &d)) != HRPT_OK) return r;      // the old, smaller buffer stays in the scene's allocation list
+        c->view.lights = d; c->lightCapacity = count;
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(const_cast<HrptGPULight*>(c->view.lights), lights, (size_t)count * sizeof(HrptGPULight), hipMemcpyHostToDevice, c->stream));
     }
-    for (uint32_t i = 0; i < s->lightCount; ++i) if (s->lights[i].m_Type != HRPT_LIGHT_DIRECTIONAL) c->traits.directionalLightsOnly = false;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->view.lightCount = count;
+    c->keptLights.assign(lights, lights + count);
+    refresh_traits(c);
+    return HRPT_OK;
+}
+
+static int update_materials_impl(HrptContext* c, const HrptMaterialConstants* materials, uint32_t firstMaterial, uint32_t count)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_materials: no scene uploaded");
+    if (count == 0) return HRPT_OK;
+    if (!materials) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_materials: null material array");
+    if ((uint64_t)firstMaterial + count > c->keptMaterials.size()) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_materials: range exceeds the scene's material count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // The acceleration structure caches two things of a material: whether its triangles are opaque (any-hit / candidate handling) and
+    // whether any material needs tangent frames. A change of either needs a rebuild; everything else is a plain buffer write.
+    HrptSceneDesc before = kept_scene_desc(c);
+    const bool tangentsBefore = scene_needs_tangents(before);
+    bool structural = false;
+    for (uint32_t i = 0; i < count; ++i)
+        if ((materials[i].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE) != (c->keptMaterials[firstMaterial + i].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE)) structural = true;
+    std::memcpy(c->keptMaterials.data() + firstMaterial, materials, (size_t)count * sizeof(HrptMaterialConstants));
+    HIP_TRY(c, hipMemcpyAsync(const_cast<HrptMaterialConstants*>(c->view.materials) + firstMaterial, materials, (size_t)count * sizeof(HrptMaterialConstants), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HrptSceneDesc s = kept_scene_desc(c);
+    if (scene_needs_tangents(s) != tangentsBefore) structural = true;
+    if (structural) {
+        SceneView v = c->view;
+        int r = build_acceleration(c, s, kept_triangle_count(c), v, true);     // from scratch: the GPU builder's resident instance table holds the opacity flags
+        if (r != HRPT_OK) { c->haveScene = false; return r; }
+        c->view = v;
+    }
+    refresh_traits(c);
     return HRPT_OK;
 }
 
@@ -338,16 +420,8 @@ static int update_instances_impl(HrptContext* c, const HrptPerInstanceData* inst
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));        // frames in flight still traverse the old tree
     std::memcpy(c->keptInstances.data() + firstInstance, instances, (size_t)count * sizeof(HrptPerInstanceData));
-    HrptSceneDesc s{};
-    s.vertices = c->keptVertices.data(); s.vertexCount = (uint32_t)c->keptVertices.size();
-    s.indices = c->keptIndices.data(); s.indexCount = (uint32_t)c->keptIndices.size();
-    s.meshData = c->keptMeshData.data(); s.meshDataCount = (uint32_t)c->keptMeshData.size();
-    s.instances = c->keptInstances.data(); s.instanceCount = (uint32_t)c->keptInstances.size();
-    s.materials = c->keptMaterials.data(); s.materialCount = (uint32_t)c->keptMaterials.size();
-    static const HrptGPULight noLight{};                 // lights play no part in the build; validate_scene only wants the array to exist
-    s.lights = &noLight; s.lightCount = 1;
-    uint64_t sceneTris = 0;
-    for (const HrptPerInstanceData& in : c->keptInstances) sceneTris += c->keptMeshData[in.m_MeshDataIndex].m_IndexCounts[0] / 3;
+    HrptSceneDesc s = kept_scene_desc(c);
+    const uint64_t sceneTris = kept_triangle_count(c);
     SceneView v = c->view;
     int r = build_acceleration(c, s, sceneTris, v, false);
     if (r != HRPT_OK) { c->haveScene = false; return r; }   // the old tree is gone: the scene has to be uploaded again
@@ -394,6 +468,7 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     if (!c->haveScene) return fail(c, HRPT_ERR_NO_SCENE, "hrpt_render: no scene uploaded");
     if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: hrpt_resize not called");
     if (p->accumCount == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: accumCount == 0");
+    if (p->constants.m_LightCount > c->view.lightCount) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_LightCount exceeds the scene's light buffer");
     uint32_t vw = (uint32_t)p->constants.m_View.m_ViewportSize[0], vh = (uint32_t)p->constants.m_View.m_ViewportSize[1];
     if (vw != c->width || vh != c->height) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_ViewportSize does not match hrpt_resize");
     TileRect rect{ p->tileX0, p->tileY0, p->tileX1, p->tileY1 };
@@ -436,6 +511,18 @@ int hrpt_update_instances(HrptContext* c, const HrptPerInstanceData* instances, 
     try { return update_instances_impl(c, instances, firstInstance, count); }
     catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_update_instances: host allocation failed"); }
     catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_update_instances: ") + e.what()); }
+}
+int hrpt_update_lights(HrptContext* c, const HrptGPULight* lights, uint32_t count)
+{
+    try { return update_lights_impl(c, lights, count); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_update_lights: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_update_lights: ") + e.what()); }
+}
+int hrpt_update_materials(HrptContext* c, const HrptMaterialConstants* materials, uint32_t firstMaterial, uint32_t count)
+{
+    try { return update_materials_impl(c, materials, firstMaterial, count); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_update_materials: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_update_materials: ") + e.what()); }
 }
 int hrpt_render(HrptContext* c, const HrptFrameParams* p)
 {

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -55,6 +55,8 @@ lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
 lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
 lib.hrpt_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+lib.hrpt_update_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+lib.hrpt_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_post_process.argtypes = [C.c_void_p, C.POINTER(S.PostParams)]
@@ -188,6 +190,18 @@ class PathTracerContext:
         instances = np.ascontiguousarray(instances)
         assert instances.dtype.itemsize == 160, "PerInstanceData records expected"
         self._check(lib.hrpt_update_instances(self._h, instances.ctypes.data, int(first), len(instances)))
+
+    def update_lights(self, lights):
+        """Replaces the light buffer (GPULight records; the count may change)."""
+        lights = np.ascontiguousarray(lights)
+        assert lights.dtype.itemsize == 64, "GPULight records expected"
+        self._check(lib.hrpt_update_lights(self._h, lights.ctypes.data, len(lights)))
+
+    def update_materials(self, materials, first=0):
+        """New constants for the materials [first, first + len(materials)) (MaterialConstants records)."""
+        materials = np.ascontiguousarray(materials)
+        assert materials.dtype.itemsize == 180, "MaterialConstants records expected"
+        self._check(lib.hrpt_update_materials(self._h, materials.ctypes.data, int(first), len(materials)))
 
     def build_info(self):
         bi = S.BuildInfo()

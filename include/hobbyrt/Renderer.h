@@ -92,6 +92,8 @@ struct Renderer {
     // src/Renderer.cpp:915-971: hands the scene's dirty instance range to the library (hrpt_update_instances: instance records +
     // acceleration-structure rebuild, the reference's writeBuffer pair + TLASRenderer) and resets the range. Returns an HrptStatus.
     int UploadDirtyInstanceTransforms();
+    // src/Renderer.cpp:976-1025: MaterialConstantsFromMaterial for the dirty range -> hrpt_update_materials; resets the range
+    int UploadDirtyMaterialConstants();
     int m_LastStatus = 0;
 };
 extern Renderer g_Renderer;

@@ -109,6 +109,10 @@ public:
     std::pair<uint32_t, uint32_t> m_InstanceDirtyRange{ UINT32_MAX, 0 };
     bool AreInstanceTransformsDirty() const { return m_InstanceDirtyRange.first <= m_InstanceDirtyRange.second; }
     void SetNodeWorldTransform(int nodeIndex, const Matrix& world);
+    // Scene::m_LightsDirty (consumed at src/Renderer.cpp:500-504) and the closed material dirty range of the emissive animations
+    // (src/Scene.cpp:440-470, consumed by Renderer::UploadDirtyMaterialConstants, src/Renderer.cpp:976-1025)
+    bool m_LightsDirty = false;
+    std::pair<uint32_t, uint32_t> m_MaterialDirtyRange{ UINT32_MAX, 0 };
 
     Vector3 GetSunDirection() const;
     void UpdateNodeBoundingSphere(int nodeIndex);   // node sphere = mesh sphere through the node's world transform

@@ -297,6 +297,16 @@ int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
  * PathTracerRenderer::Render's reset on a changed view matrix (src/PathTracerRenderer.cpp:41-50), restarting accumulation
  * (firstAccumulationIndex = 0) is the caller's decision. If the rebuild fails the scene is unusable until hrpt_upload_scene. */
 int  hrpt_update_instances(HrptContext* ctx, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count);
+/* The other two per-frame uploads of the reference's main loop (src/Renderer.cpp:500-507):
+ * hrpt_update_lights replaces the whole light buffer, like SceneLoader::CreateAndUploadLightBuffer when Scene::m_LightsDirty is set
+ * (count may differ from the uploaded scene's; at least one light; HrptPathTracerConstants::m_LightCount of later frames must not
+ * exceed it). hrpt_update_materials writes materials[0..count) over the material constants [firstMaterial, firstMaterial + count),
+ * the closed dirty range of Renderer::UploadDirtyMaterialConstants (src/Renderer.cpp:976-1025; emissive animations mark it,
+ * src/Scene.cpp:440-470). Texture indices keep referring to the uploaded texture table. A material that switches between OPAQUE and
+ * MASK / BLEND, or the first material with a normal map, changes what the acceleration structure caches per triangle: the call then
+ * rebuilds it (as hrpt_update_instances would); anything else is a buffer write. Both wait for frames in flight. */
+int  hrpt_update_lights(HrptContext* ctx, const HrptGPULight* lights, uint32_t count);
+int  hrpt_update_materials(HrptContext* ctx, const HrptMaterialConstants* materials, uint32_t firstMaterial, uint32_t count);
 
 /* ---- in-process multi-GPU: one context per GPU inside ONE process ------------------------------------
  * Rank i of n has rendered the row band [i*H/n, (i+1)*H/n) of its accumulation image (HrptFrameParams::tile*; H must be a

@@ -143,3 +143,70 @@ def test_update_errors(luts):
         _assert_parity(*_render_pair(c, sc, view, pos, 32, 18, 1, 2, S.FRAME_DEFAULT))   # the scene is still intact after the rejected calls
     finally:
         c.close()
+
+
+# ---- hrpt_update_lights / hrpt_update_materials: the other two per-frame uploads of the reference's main loop (src/Renderer.cpp:500-507)
+def test_update_lights_matches_a_fresh_scene(luts):
+    from hobbyrenderer_amd.native import PathTracerContext
+    plain, view, pos, cfg = scenes.config_cornell(luts, 96, 54)
+    lit = scenes.config_cornell(luts, 96, 54, extra_lights=True)[0]           # same geometry, sun + point + spot
+    assert len(lit.lights) > len(plain.lights) and plain.vertices.tobytes() == lit.vertices.tobytes()
+    c = PathTracerContext(0)
+    try:
+        c.upload_scene(plain)
+        c.update_lights(lit.lights)                                            # more lights than uploaded: the buffer grows
+        _assert_parity(*_render_pair(c, lit, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+        _assert_parity(*_render_pair(c, lit, view, pos, 96, 54, 1, 2, S.FRAME_MEGAKERNEL))
+        dim = copy.copy(lit)
+        dim.lights = lit.lights.copy()
+        dim.lights["m_Intensity"] *= np.float32(0.25)
+        dim.lights["m_Color"][:, 1] *= np.float32(0.5)
+        c.update_lights(dim.lights)                                            # same count: written in place
+        _assert_parity(*_render_pair(c, dim, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+        c.update_lights(plain.lights)                                          # back to the sun alone (single-light kernels again)
+        _assert_parity(*_render_pair(c, plain, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+        with pytest.raises(Exception, match="m_LightCount"):
+            c.render(scenes.fill_constants(view, pos, lit, 0, 2), accum_count=1)   # 3 lights asked for, 1 in the buffer
+        with pytest.raises(Exception, match="at least one light"):
+            c.update_lights(plain.lights[:0])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("builder", [S.BVH_BUILDER_HOST_SAH, S.BVH_BUILDER_GPU_LBVH], ids=["host", "lbvh"])
+def test_update_materials_matches_a_fresh_scene(luts, builder):
+    from hobbyrenderer_amd.native import PathTracerContext
+    sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54)
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(builder)
+        c.upload_scene(sc)
+        # plain constants: brighter lamp, a metallic wall (no structural change)
+        a = copy.copy(sc)
+        a.materials = sc.materials.copy()
+        lamp = int(np.argmax(a.materials["m_EmissiveFactor"][:, 0]))
+        a.materials["m_EmissiveFactor"][lamp, :3] *= np.float32(1.5)           # what the reference's emissive animation changes
+        a.materials["m_RoughnessMetallic"][0] = (0.3, 1.0)
+        first, last = min(0, lamp), max(0, lamp)
+        c.update_materials(a.materials[first:last + 1], first)
+        _assert_parity(*_render_pair(c, a, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+        # structural: one box becomes glass (BLEND + transmission: non-opaque triangles, medium tracking, general shade variant)
+        b = copy.copy(a)
+        b.materials = a.materials.copy()
+        box = int(sc.instances["m_MaterialIndex"][-1])
+        b.materials["m_AlphaMode"][box] = S.ALPHA_MODE_BLEND
+        b.materials["m_TransmissionFactor"][box] = 1.0
+        b.materials["m_IOR"][box] = 1.5
+        b.materials["m_RoughnessMetallic"][box] = (0.04, 0.0)
+        c.update_materials(b.materials[box:box + 1], box)
+        bi = c.build_info()
+        assert bi.usedBuilder == builder
+        _assert_parity(*_render_pair(c, b, view, pos, 96, 54, 2, 6, S.FRAME_DEFAULT))
+        _assert_parity(*_render_pair(c, b, view, pos, 96, 54, 1, 4, S.FRAME_MEGAKERNEL))
+        # and opaque again
+        c.update_materials(a.materials[box:box + 1], box)
+        _assert_parity(*_render_pair(c, a, view, pos, 96, 54, 1, cfg["max_bounces"], S.FRAME_DEFAULT))
+        with pytest.raises(Exception, match="range"):
+            c.update_materials(a.materials, first=1)
+    finally:
+        c.close()
