@@ -468,6 +468,7 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     if (!c->haveScene) return fail(c, HRPT_ERR_NO_SCENE, "hrpt_render: no scene uploaded");
     if (!c->dAccum) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: hrpt_resize not called");
     if (p->accumCount == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: accumCount == 0");
+    if (p->constants.m_MaxBounces > 64u) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_MaxBounces above 64 (the reference's UI stops at 12, src/ImGuiLayer.cpp:760; one kernel sequence is launched per bounce)");
     if (p->constants.m_LightCount > c->view.lightCount) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_LightCount exceeds the scene's light buffer");
     uint32_t vw = (uint32_t)p->constants.m_View.m_ViewportSize[0], vh = (uint32_t)p->constants.m_View.m_ViewportSize[1];
     if (vw != c->width || vh != c->height) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_ViewportSize does not match hrpt_resize");

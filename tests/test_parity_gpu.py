@@ -136,6 +136,12 @@ def test_error_paths(ctx, luts):
     with pytest.raises(HrptError):
         ctx.upload_scene(bad)
     ctx.upload_scene(sc)   # context still usable
+    with pytest.raises(HrptError, match="m_MaxBounces"):
+        ctx.render(scenes.fill_constants(view, pos, sc, 0, 100000))
+    two = scenes.fill_constants(view, pos, sc, 0, 1)
+    two["m_LightCount"] = 2                                   # more lights than the scene's buffer holds
+    with pytest.raises(HrptError, match="m_LightCount"):
+        ctx.render(two)
     ctx.render(scenes.fill_constants(view, pos, sc, 0, 1))
     assert np.isfinite(ctx.read_output()).all()
 
