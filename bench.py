@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
                     help="independent steps (frames) in flight on each GPU: 2 = consecutive steps alternate between two path-tracer contexts "
                          "(own streams, queues and images) so that one frame's kernel tails overlap the other's; 1 = one frame at a time")
+    ap.add_argument("--sharding", choices=("columns", "rows"), default="columns",
+                    help="N>1: interleaved 8-pixel columns (every rank covers the whole picture: balanced) or contiguous row bands")
     ap.add_argument("--force-sharded", action="store_true", help="testing: run the N>1 code path (RCCL all-gather, comm stream) with a single rank")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json config: 2 = headline (Cornell-class), 4 = Sponza-class stand-in, 5 = glass stress stand-in")
@@ -132,7 +134,7 @@ def main():
     flags = {"default": S.FRAME_DEFAULT, "megakernel": S.FRAME_MEGAKERNEL, "wavefront": S.FRAME_WAVEFRONT}[args.mode]
 
     # row-band sharding (hobbyrenderer_amd/distributed.py); bands are contiguous in the row-major accumulation image
-    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank, device_tensor, render_sharded
+    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank, column_view, device_tensor, render_sharded
     y0, y1 = band_for_rank(H, world, rank)
     rows = y1 - y0
     accum_ptr, _ = ctx.device_images()
@@ -160,9 +162,13 @@ def main():
         else:
             ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
+    # column interleaving needs the pipelined path (its gather re-assembles the image) and a width divisible by 8 * ranks
+    columns = pipelined and args.sharding == "columns" and W % (8 * world) == 0
+    stripes = (world, rank) if columns else (1, 0)
+
     def band_renderer(c):
         def render_band(b0, b1):
-            c.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags)
+            c.render(cb, accum_count=spp, tile=(0, b0, W, b1), flags=flags, stripes=stripes)
             if not same_stream:
                 c.synchronize()                                 # library stream -> host before the host-staged gather
         return render_band
@@ -171,10 +177,11 @@ def main():
     frames = None
     if pipelined:
         # frame k's all-gather + resolve run on a second stream while frame k+1 renders (hobbyrenderer_amd/distributed.py)
-        views = [device_tensor(c.device_images()[0], (H, W, 4), dev)[y0:y1] for c in lanes]
+        images = [device_tensor(c.device_images()[0], (H, W, 4), dev) for c in lanes]
+        views = [column_view(im, world, rank) if columns else im[y0:y1] for im in images]
         frames = PipelinedFrames([band_renderer(c) for c in lanes], views, H, W, rank, world, all_gather,
                                  lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), H * W, stream), dev,
-                                 lane_streams=lane_streams)
+                                 lane_streams=lane_streams, layout="columns" if columns else "rows")
     step_no = [0]
 
     def step():
@@ -223,7 +230,7 @@ def main():
         prof_steps = 3
         ctx.reset_stats()
         for _ in range(prof_steps):
-            ctx.render(cb, accum_count=spp, tile=(0, y0, W, y1) if sharded else (0, 0, 0, 0), flags=flags | S.FRAME_PROFILE)
+            ctx.render(cb, accum_count=spp, tile=((0, 0, W, H) if columns else (0, y0, W, y1)) if sharded else (0, 0, 0, 0), flags=flags | S.FRAME_PROFILE, stripes=stripes)
         ctx.synchronize()
         pst = ctx.stats()
 
@@ -245,7 +252,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not rehearse else "REHEARSAL on one GPU (gloo through host): not a result",
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
-                       "sharding": f"{world} row band(s) of {rows} rows, BVH+scene replicated" + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
+                       "sharding": (f"{world} rank(s), 8-pixel columns interleaved (column k on rank k mod {world}), BVH+scene replicated" if columns else f"{world} row band(s) of {rows} rows, BVH+scene replicated") + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
                        "frames_in_flight": len(lanes),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
@@ -275,7 +282,7 @@ def main():
         b_closest = 768.0 + 32.0 * n_c + 48.0 * t_c
         b_shadow = 36.0 + 32.0 * n_s + 48.0 * t_s
         r0_closest, r0_shadow = float(st.closestRays) / args.steps, float(st.shadowRays) / args.steps   # rank 0, per step
-        px0 = (y1 - y0) * W if sharded else W * H
+        px0 = (W * H // world if columns else (y1 - y0) * W) if sharded else W * H
         step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
         if prof_steps and pst.traceKernelLaunches > 0:
             # wavefront: per-class device time from HIP events the library records on ITS stream around every launch.

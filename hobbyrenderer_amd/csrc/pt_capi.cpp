@@ -472,7 +472,9 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     if (p->constants.m_LightCount > c->view.lightCount) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_LightCount exceeds the scene's light buffer");
     uint32_t vw = (uint32_t)p->constants.m_View.m_ViewportSize[0], vh = (uint32_t)p->constants.m_View.m_ViewportSize[1];
     if (vw != c->width || vh != c->height) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: m_ViewportSize does not match hrpt_resize");
-    TileRect rect{ p->tileX0, p->tileY0, p->tileX1, p->tileY1 };
+    TileRect rect; rect.x0 = p->tileX0; rect.y0 = p->tileY0; rect.x1 = p->tileX1; rect.y1 = p->tileY1;
+    rect.stripeCount = p->stripeCount ? p->stripeCount : 1u; rect.stripeIndex = p->stripeIndex;
+    if (rect.stripeIndex >= rect.stripeCount) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: stripeIndex must be below stripeCount");
     if (rect.x0 == 0 && rect.y0 == 0 && rect.x1 == 0 && rect.y1 == 0) { rect.x1 = c->width; rect.y1 = c->height; }
     if (rect.x1 > c->width || rect.y1 > c->height || rect.x0 > rect.x1 || rect.y0 > rect.y1)
         return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: tile rectangle outside the image");

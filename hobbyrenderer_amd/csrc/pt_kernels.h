@@ -18,7 +18,13 @@ struct DeviceCounters {         // 32 B; summed over the shards by hrpt_get_stat
     unsigned long long pad;
 };
 
-struct TileRect { uint32_t x0, y0, x1, y1; };
+struct TileRect {
+    uint32_t x0, y0, x1, y1;
+    uint32_t stripeCount = 1, stripeIndex = 0;     // of the rectangle's 8-pixel columns, those with column % stripeCount == stripeIndex
+    // number of 8-pixel columns this call covers / pixel column of its k-th one
+    __host__ __device__ uint32_t columns() const { uint32_t all = (x1 - x0 + 7u) / 8u; return all > stripeIndex ? (all - stripeIndex + stripeCount - 1u) / stripeCount : 0u; }
+    __host__ __device__ uint32_t column_x(uint32_t k) const { return x0 + (k * stripeCount + stripeIndex) * 8u; }
+};
 
 // One dispatch of the reference shader: one path per pixel of `rect` for constants.m_AccumulationIndex.
 // Validation path: one thread per pixel, private traversal stack.

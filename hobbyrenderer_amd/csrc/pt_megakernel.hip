@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerC
 {
     // 8x8 pixel tile per 64-lane wave (same footprint as [numthreads(8,8,1)], PathTracer.hlsl:52)
     uint32_t lx = threadIdx.x & 7u, ly = threadIdx.x >> 3;
-    uint32_t px = rect.x0 + blockIdx.x * 8u + lx, py = rect.y0 + blockIdx.y * 8u + ly;
+    uint32_t px = rect.column_x(blockIdx.x) + lx, py = rect.y0 + blockIdx.y * 8u + ly;
     bool active = px < rect.x1 && py < rect.y1;
     unsigned int nClosest = 0, nShadow = 0;
 
@@ -102,8 +102,8 @@ __global__ void pt_resolve_kernel(const float4* __restrict__ accumulation, float
 hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation, float4* output,
                              uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream)
 {
-    if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0) return hipSuccess;
-    dim3 grid((rect.x1 - rect.x0 + 7) / 8, (rect.y1 - rect.y0 + 7) / 8, 1);
+    if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0 || rect.columns() == 0) return hipSuccess;
+    dim3 grid(rect.columns(), (rect.y1 - rect.y0 + 7) / 8, 1);
     hipLaunchKernelGGL(pt_megakernel, grid, dim3(64, 1, 1), 0, stream, scene, constants, accumulation, output, imageWidth, rect, counters);
     return hipGetLastError();
 }

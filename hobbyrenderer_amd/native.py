@@ -98,7 +98,7 @@ class PathTracerContext:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
-        desc = S.DeviceDesc(device, 1)
+        desc = S.DeviceDesc(device, S.ABI_VERSION)
         rc = lib.hrpt_create(C.byref(desc), C.byref(self._h))
         if rc != 0:
             raise HrptError(rc, lib.hrpt_last_error(None).decode())
@@ -128,8 +128,10 @@ class PathTracerContext:
         self._check(lib.hrpt_resize(self._h, width, height))
         self.width, self.height = width, height
 
-    def render(self, constants, accum_count=1, tile=(0, 0, 0, 0), flags=S.FRAME_DEFAULT):
+    def render(self, constants, accum_count=1, tile=(0, 0, 0, 0), flags=S.FRAME_DEFAULT, stripes=(1, 0)):
+        """stripes = (count, index): of the tile's 8-pixel columns only those with column % count == index are rendered."""
         p = np.zeros((), S.FrameParams)
+        p["stripeCount"], p["stripeIndex"] = stripes
         p["constants"] = constants
         p["accumCount"] = accum_count
         p["tileX0"], p["tileY0"], p["tileX1"], p["tileY1"] = tile

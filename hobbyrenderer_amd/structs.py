@@ -43,7 +43,7 @@ PathTracerConstants = np.dtype([
     ("m_FrameIndex", u32), ("m_MaxBounces", u32), ("m_Jitter", f32, 2), ("m_Pad0", f32, 2), ("m_SunDirection", f32, 3),
     ("m_CosSunAngularRadius", f32)])
 FrameParams = np.dtype([("constants", PathTracerConstants), ("accumCount", u32), ("tileX0", u32), ("tileY0", u32),
-                        ("tileX1", u32), ("tileY1", u32), ("flags", u32)])
+                        ("tileX1", u32), ("tileY1", u32), ("flags", u32), ("stripeCount", u32), ("stripeIndex", u32)])
 
 assert VertexQuantized.itemsize == 24 and MeshData.itemsize == 164 and PerInstanceData.itemsize == 160
 assert MaterialConstants.itemsize == 180 and GPULight.itemsize == 64
@@ -105,6 +105,7 @@ class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
                 ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("pad", C.c_uint32 * 1)]
 
 
+ABI_VERSION = 2                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)
 BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC, BVH_BUILDER_AUTO = 0, 1, 2, 3
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HRPT_ABI_VERSION 1
+#define HRPT_ABI_VERSION 2
 
 typedef enum HrptStatus {
     HRPT_OK = 0,
@@ -210,6 +210,10 @@ typedef struct HrptFrameParams {
     /* pixel rectangle [x0,x1) x [y0,y1) rendered by this context (image-tile sharding); 0,0,0,0 = full viewport */
     uint32_t tileX0, tileY0, tileX1, tileY1;
     uint32_t flags;                        /* HRPT_FRAME_* */
+    /* column interleaving inside the rectangle (multi-GPU load balance): the rectangle is cut into columns of 8 pixels
+     * (the reference's thread-group width, PathTracer.hlsl:52) and only the columns k with k % stripeCount == stripeIndex are rendered;
+     * every rank then works on all parts of the image. stripeCount 0 or 1 = the whole rectangle. Pixels outside are not touched. */
+    uint32_t stripeCount, stripeIndex;
 } HrptFrameParams;
 
 enum {

@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_sizes_match_header():
     assert C.sizeof(S.SceneDesc) == 136 and C.sizeof(S.TextureDesc) == 16 and C.sizeof(S.DeviceDesc) == 8
-    assert S.FrameParams.itemsize == 768 + 6 * 4
+    assert S.FrameParams.itemsize == 768 + 8 * 4
     assert C.sizeof(S.Stats) == 64
 
 

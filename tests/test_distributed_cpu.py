@@ -53,14 +53,14 @@ def test_two_rank_band_sharding_matches_single_rank(tmp_path, luts):
     assert np.array_equal(a1.view(np.uint32), ref.view(np.uint32))
 
 
-def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1):
+def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1, layout="rows"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hobbyrenderer_amd import native, scenes
-    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank
+    from hobbyrenderer_amd.distributed import PipelinedFrames, band_for_rank, column_view
     from oracle.binding import Oracle
     luts = native.precompute_atmosphere(2)
     sc, view, pos, _ = scenes.config_cornell(luts, w, h)
@@ -73,6 +73,10 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1):
         def render_band(y0, y1):   # frame f = accumulation index f alone, restarted from zero (three different frames)
             acc[y0:y1] = 0.0
             o.render(scenes.fill_constants(view, pos, sc, state["first"], bounces), acc, out, (0, y0, w, y1), nthreads=2)
+            if layout == "columns":    # the oracle has no stripe mode: keep this rank's 8-pixel columns, clear the others
+                cols = acc.reshape(h, w // 8, 8, 4)
+                keep = np.zeros(w // 8, bool); keep[rank::world] = True
+                cols[:, ~keep] = 0.0
         return render_band
 
     def resolve(a, b, stream):
@@ -80,8 +84,9 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1):
 
     y0, y1 = band_for_rank(h, world, rank)
     fulls = [torch.from_numpy(a) for a in accs]
-    frames = PipelinedFrames([band_renderer(a) for a in accs], [f[y0:y1] for f in fulls], h, w, rank, world,
-                             lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"))
+    views = [column_view(f, world, rank) if layout == "columns" else f[y0:y1] for f in fulls]
+    frames = PipelinedFrames([band_renderer(a) for a in accs], views, h, w, rank, world,
+                             lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"), layout=layout)
     for f in range(3):
         state["first"] = f
         slot = frames.submit()
@@ -92,15 +97,15 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_two_rank_pipelined_frames(tmp_path, luts, lanes):
+@pytest.mark.parametrize("lanes,layout", [(1, "rows"), (2, "rows"), (2, "columns")])
+def test_two_rank_pipelined_frames(tmp_path, luts, lanes, layout):
     """PipelinedFrames bookkeeping (double-buffered staging / gathered images; one or two lanes = contexts alternating frame by
     frame) under gloo, world 2: every frame of every rank equals the single-rank image of that accumulation index."""
     from hobbyrenderer_amd import scenes
     from oracle.binding import Oracle
     w, h, bounces = 48, 28, 3
     port = 30100 + (os.getpid() % 500)
-    mp.spawn(_pipelined_worker, args=(2, port + lanes, w, h, bounces, str(tmp_path), lanes), nprocs=2, join=True)
+    mp.spawn(_pipelined_worker, args=(2, port + lanes + (7 if layout == "columns" else 0), w, h, bounces, str(tmp_path), lanes, layout), nprocs=2, join=True)
     sc, view, pos, _ = scenes.config_cornell(luts, w, h)
     o = Oracle(sc)
     for f in range(3):

@@ -103,10 +103,70 @@ def test_device_tensor_view_and_rccl_allgather(luts):
             ref_ctx.close()
             assert np.array_equal(frames.gathered[slot].cpu().numpy().view(np.uint32), ra.view(np.uint32)), f
             assert np.array_equal(frames.output[slot].cpu().numpy().view(np.uint32), ro.view(np.uint32)), f
+        # the column layout through the same streams (world 1: every column is this rank's): stripes + strided staging copy + re-assembly
+        from hobbyrenderer_amd.distributed import column_view
+
+        def lane_render_cols(c):
+            return lambda a, b: c.render(scenes.fill_constants(view, pos, sc, 0, 4), accum_count=count["n"], tile=(0, a, 128, b), stripes=(1, 0))
+        cviews = [column_view(device_tensor(c.device_images()[0], (72, 128, 4), dev), 1, 0) for c in lanes]
+        frames = PipelinedFrames([lane_render_cols(c) for c in lanes], cviews, 72, 128, 0, 1, lambda f, b: dist.all_gather_into_tensor(f, b),
+                                 lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), 72 * 128, stream), dev, lane_streams=streams,
+                                 layout="columns")
+        for f in range(3):
+            count["n"] = f + 2
+            slot = frames.submit()
+        frames.finish()
+        torch.cuda.synchronize(dev)
+        ref_ctx = PathTracerContext(0)
+        ref_ctx.upload_scene(sc); ref_ctx.resize(128, 72)
+        ref_ctx.render(scenes.fill_constants(view, pos, sc, 0, 4), accum_count=4)
+        assert np.array_equal(frames.gathered[slot].cpu().numpy().view(np.uint32), ref_ctx.read_accumulation().view(np.uint32))
+        assert np.array_equal(frames.output[slot].cpu().numpy().view(np.uint32), ref_ctx.read_output().view(np.uint32))
+        ref_ctx.close()
         ctx2.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flags", [S.FRAME_DEFAULT, S.FRAME_MEGAKERNEL], ids=["wavefront", "megakernel"])
+def test_column_interleaved_shards_assemble_to_the_full_image(luts, flags):
+    """hrpt_render stripeCount / stripeIndex + distributed.column_view / columns_to_image: n ranks (here n contexts on one GPU) each
+    render the 8-pixel columns k with k % n == rank; staging copies, a rank-major concatenation (what the all-gather delivers) and
+    the re-assembly give the single-context image bit for bit. Widths that are not a multiple of 8 * n are refused."""
+    import torch
+    from hobbyrenderer_amd.distributed import column_view, columns_to_image, device_tensor
+    from hobbyrenderer_amd.native import HrptError, PathTracerContext
+    w, h, n, spp = 96, 40, 3, 2                                   # 12 columns of 8 pixels over 3 ranks
+    sc, view, pos, cfg = scenes.config_cornell(luts, w, h)
+    cb = scenes.fill_constants(view, pos, sc, 0, 4)
+    dev = torch.device("cuda", 0)
+    ref = PathTracerContext(0); ref.upload_scene(sc); ref.resize(w, h)
+    ref.render(cb, accum_count=spp, flags=flags)
+    want = ref.read_accumulation()
+    shards = []
+    for r in range(n):
+        c = PathTracerContext(0); c.upload_scene(sc); c.resize(w, h)
+        c.render(cb, accum_count=spp, flags=flags, stripes=(n, r))
+        c.synchronize()
+        img = device_tensor(c.device_images()[0], (h, w, 4), dev)
+        mine = column_view(img, n, r)
+        assert mine.shape == (h, w // 8 // n, 8, 4)
+        host = c.read_accumulation().reshape(h, w // 8, 8, 4)
+        others = np.delete(host, np.arange(r, w // 8, n), axis=1)
+        assert (others == 0).all()                               # columns of other ranks are not touched
+        shards.append(mine.contiguous())
+        c.close()
+    out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    columns_to_image(torch.stack(shards).reshape(-1), n, out)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with pytest.raises(HrptError, match="stripeIndex"):
+        ref.render(cb, accum_count=1, stripes=(2, 2))
+    with pytest.raises(ValueError):
+        column_view(torch.empty((h, 100, 4)), n, 0)
+    # a rectangle narrower than the stripe pattern: ranks beyond its columns render nothing and succeed
+    ref.render(cb, accum_count=1, tile=(0, 0, 10, h), stripes=(4, 3))
+    ref.close()
 
 
 def test_in_process_allgather_of_bands(luts):
