@@ -146,6 +146,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_PAD_LDS")) c->wf.padLdsBytes = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_DRAIN_SEGMENTS")) c->wf.drainSegments = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
+    if (const char* e = getenv("HRPT_WF_SHADOW_PATH")) c->wf.shadowPath = atoi(e);
     *out = c;
     return HRPT_OK;
 }
@@ -272,7 +273,9 @@ static void refresh_traits(HrptContext* c)
     SceneTraits t; t.bvhMaxDepth = c->traits.bvhMaxDepth; t.bvh4MaxDepth = c->traits.bvh4MaxDepth;
     for (const HrptPerInstanceData& in : c->keptInstances) {
         const HrptMaterialConstants& m = c->keptMaterials[in.m_MaterialIndex];
-        if (m.m_TransmissionFactor > 0.0f && m.m_IsThinSurface == 0) t.hasMedium = true;
+        // the transmission branch (PathTracer.hlsl:149-255) is entered for transmissive AND for BLEND materials (effective transmission
+        // 1 - alpha), and a thick one switches the path's medium state there: that state then has to travel with the path
+        if ((m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) && m.m_IsThinSurface == 0) t.hasMedium = true;
         if (m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND && !(m.m_TransmissionFactor > 0.0f)) t.hasStochasticAlpha = true;
         if (m.m_TextureFlags != 0) t.hasTextures = true;
         if (m.m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) t.hasNonOpaque = true;

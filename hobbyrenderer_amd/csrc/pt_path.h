@@ -150,50 +150,34 @@ HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L
 // candidates, sorted by (t, inst, prim), into a per-lane buffer CAND (LDS columns of (t, triangle)); they are then processed front to
 // back without further traversals. More than K candidates: the re-trace loop continues behind the K-th. Same visiting
 // order as the re-trace form, hence the same result.
-template <int K, class BVH, class STACK, class CAND>
-HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, CAND& cand)
+// (t, triangle) of a non-opaque hit into the per-lane buffer of the K smallest keys, kept sorted; `overflow` once a hit did not fit.
+template <int K, class BVH, class CAND>
+HRT_DEV void candidate_insert(const BVH& bvh, CAND& cand, int& count, bool& overflow, float t, uint32_t tri, uint32_t inst, uint32_t prim)
 {
-    Ray ray = shadow_ray(worldPos, L, maxDist);
-    if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
-    RayShear sh = make_shear(ray.d);
-    f3 inv = traversal_rcp(ray.d), noi = slab_origin_term(ray.o, inv);
-    int sp = 0, count = 0; bool overflow = false;
-    int32_t cur;
-    if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
-    for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, ray.tmin, ray.tmax, stack, sp);
-        if (cur == kTraversalDone) break;
-        uint32_t enc = (uint32_t)(~cur);
-        uint32_t first = enc >> 2, n = (enc & 3u) + 1u;
-        for (uint32_t i = 0; i < n; ++i) {
-            float4 a, b, c; bvh.tri(first + i, a, b, c);
-            float t, u, v;
-            if (!tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, sh, t, u, v)) continue;
-            if (__float_as_uint(c.w) & 1u) return 0.0f;                           // opaque instance: committed
-            // insert (t, tri, u, v) keeping the K smallest keys sorted
-            uint32_t inst = __float_as_uint(a.w), prim = __float_as_uint(b.w);
-            int pos = count;
-            if (count == K) {
-                float lt; uint32_t ltri; cand.key(K - 1, lt, ltri);
-                float4 la, lb, lc; bvh.tri(ltri, la, lb, lc);
-                overflow = true;
-                if (!key_less(t, inst, prim, lt, __float_as_uint(la.w), __float_as_uint(lb.w))) continue;
-                pos = K - 1;
-            } else ++count;
-            while (pos > 0) {
-                float pt; uint32_t ptri; cand.key(pos - 1, pt, ptri);
-                bool less;
-                if (t != pt) less = t < pt;
-                else { float4 pa, pb, pc; bvh.tri(ptri, pa, pb, pc); less = key_less(t, inst, prim, pt, __float_as_uint(pa.w), __float_as_uint(pb.w)); }
-                if (!less) break;
-                cand.move(pos, pos - 1);
-                --pos;
-            }
-            cand.set(pos, t, first + i);
-        }
-        if (sp == 0) break;
-        cur = stack.pop(--sp);
+    int pos = count;
+    if (count == K) {
+        float lt; uint32_t ltri; cand.key(K - 1, lt, ltri);
+        float4 la, lb, lc; bvh.tri(ltri, la, lb, lc);
+        overflow = true;
+        if (!key_less(t, inst, prim, lt, __float_as_uint(la.w), __float_as_uint(lb.w))) return;
+        pos = K - 1;
+    } else ++count;
+    while (pos > 0) {
+        float pt; uint32_t ptri; cand.key(pos - 1, pt, ptri);
+        bool less;
+        if (t != pt) less = t < pt;
+        else { float4 pa, pb, pc; bvh.tri(ptri, pa, pb, pc); less = key_less(t, inst, prim, pt, __float_as_uint(pa.w), __float_as_uint(pb.w)); }
+        if (!less) break;
+        cand.move(pos, pos - 1);
+        --pos;
     }
+    cand.set(pos, t, tri);
+}
+// The candidates front to back (CalculateRTShadow's per-candidate body), then -- if more than K existed -- the re-trace loop behind the
+// K-th, then the closing Beer-Lambert segment. `cand.key(k, t, tri)` yields the k-th smallest key.
+template <class BVH, class STACK, class CAND>
+HRT_DEV float shadow_resolve_candidates(const SceneView& s, const BVH& bvh, const Ray& ray, const RayShear& sh, int count, bool overflow, const CAND& cand, STACK& stack)
+{
     if (count == 0) return 1.0f;
     ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
     float lastT = 0.0f; uint32_t lastTri = 0;
@@ -217,6 +201,33 @@ HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 world
         }
     }
     return shadow_finish(ray, st);
+}
+template <int K, class BVH, class STACK, class CAND>
+HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, CAND& cand)
+{
+    Ray ray = shadow_ray(worldPos, L, maxDist);
+    if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
+    RayShear sh = make_shear(ray.d);
+    f3 inv = traversal_rcp(ray.d), noi = slab_origin_term(ray.o, inv);
+    int sp = 0, count = 0; bool overflow = false;
+    int32_t cur;
+    if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
+    for (;;) {
+        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, ray.tmin, ray.tmax, stack, sp);
+        if (cur == kTraversalDone) break;
+        uint32_t enc = (uint32_t)(~cur);
+        uint32_t first = enc >> 2, n = (enc & 3u) + 1u;
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 a, b, c; bvh.tri(first + i, a, b, c);
+            float t, u, v;
+            if (!tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, sh, t, u, v)) continue;
+            if (__float_as_uint(c.w) & 1u) return 0.0f;                           // opaque instance: committed
+            candidate_insert<K>(bvh, cand, count, overflow, t, first + i, __float_as_uint(a.w), __float_as_uint(b.w));
+        }
+        if (sp == 0) break;
+        cur = stack.pop(--sp);
+    }
+    return shadow_resolve_candidates(s, bvh, ray, sh, count, overflow, cand, stack);
 }
 
 // One light of AccumulateDirectLighting (CommonLighting.hlsli:877-908) in three stages, so that a schedule may run the

@@ -43,6 +43,10 @@ struct WfBuffers {
     float4* hit;
     float4 *sh0, *sh1, *sh2, *sh3, *sh4, *shL;
     uint32_t* shadowCnt;
+    // shadow-ray stage of scenes with non-opaque geometry: one compacted ray per valid light sample {o, tmin} {d, tmax}, the (entry, light)
+    // slot it belongs to, rays per segment, and the outcome of the opaque any-hit pass per (entry, light) slot (kVis*)
+    float4 *sqO, *sqD; uint32_t* sqId; uint32_t* sqCnt; uint32_t* shVis;
+    uint2* sqCand;             // kShadowCandidates (t, triangle) keys per (entry, light) slot: the non-opaque triangles a ray crossed, nearest first
     float4* radiance;
 };
 
@@ -65,6 +69,8 @@ struct WfArgs {
     int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
     DeviceCounters* counters;
 };
+
+enum : uint32_t { kVisNoRay = 0, kVisBlocked = 1, kVisClear = 2, kVisCandidates = 3 };   // shVis codes
 
 struct JitterTable { float2 j[kMaxSppPerBatch]; };
 
@@ -108,6 +114,11 @@ struct LdsCandidates {
     HRT_DEV void key(int k, float& t, uint32_t& tri) const { t = __int_as_float(base[(k * 2 + 0) * kBlock]); tri = (uint32_t)base[(k * 2 + 1) * kBlock]; }
     HRT_DEV void set(int k, float t, uint32_t tri) { base[(k * 2 + 0) * kBlock] = __float_as_int(t); base[(k * 2 + 1) * kBlock] = (int32_t)tri; }
     HRT_DEV void move(int dst, int src) { base[(dst * 2 + 0) * kBlock] = base[(src * 2 + 0) * kBlock]; base[(dst * 2 + 1) * kBlock] = base[(src * 2 + 1) * kBlock]; }
+};
+// candidate list of one shadow ray in global memory (written by wf_extend<ANYHIT> when the ray finishes, read by wf_shadow)
+struct GlobalCandidates {
+    const uint2* base;
+    HRT_DEV void key(int k, float& t, uint32_t& tri) const { uint2 v = base[k]; t = __uint_as_float(v.x); tri = v.y; }
 };
 // BVH copy in LDS; W = node width (2: GpuNode, 4: GpuNode4)
 template <int W>
@@ -233,20 +244,27 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
 constexpr uint32_t kRefillMinDefault = 12;
 
-template <bool LDS_BVH, int DEPTH, int W>
+// ANYHIT: the same persistent loop over the shadow-ray queue (sqO / sqD / sqId, sqCnt rays per segment): the first hit on an opaque
+// triangle ends the ray (kVisBlocked); otherwise the ray is clear or, if it crossed non-opaque triangles, left to wf_shadow's candidate
+// pass (kVisCandidates). Shadow rays get the lane refill closest-hit rays have: 3.8 -> 8 Grays/s on the glass config.
+template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT>
 __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
-    setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh);
-    if (DEPTH > kExtendLdsStack) { stack.spill = a.spill[0] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
+    constexpr size_t candBytes = ANYHIT ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kLds * kBlock * 4) + threadIdx.x;
+    if (DEPTH > kExtendLdsStack) { stack.spill = a.spill[ANYHIT ? 1 : 0] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
 
     const uint32_t wavesPerBlock = kBlock / 64;
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
-    const float4* __restrict__ rayO = a.b.rayO[parity];
-    float4* __restrict__ rayD = a.b.rayD[parity];
+    const float4* __restrict__ rayO = ANYHIT ? a.b.sqO : a.b.rayO[parity];
+    float4* __restrict__ rayD = ANYHIT ? a.b.sqD : a.b.rayD[parity];
+    const uint32_t* __restrict__ segCount = ANYHIT ? a.b.sqCnt : a.b.pathCnt[parity];
+    const uint32_t slotsPerSample = ANYHIT ? a.maxLights : 1u;
     unsigned int nRays = 0;
     const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
 
@@ -258,8 +276,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
         auto open_segment = [&]() {                             // first non-empty segment at or after `seg`
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = a.b.pathCnt[parity][seg];
-                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+                cnt = segCount[seg];
+                if (cnt) { segBase = (seg << a.segShift) * slotsPerSample; haveSeg = true; break; }
             }
         };
         open_segment();
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
         HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
         Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
         int32_t cur = kTraversalDone; int sp = 0; uint32_t slot = 0, rng = 0, rng0 = 0; float tlim = 0.0f;
+        bool blocked = false, candOverflow = false; int candCount = 0;
         for (;;) {
             if (haveSeg && next >= cnt && (a.streamSegments || __ballot(active) == 0ull)) { seg += totalWaves; open_segment(); }
             // ---- refill idle lanes
@@ -280,8 +299,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                 if (!active && idx < cnt) {
                     slot = segBase + idx;
                     float4 o = rayO[slot], d = rayD[slot];
-                    r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = 1e10f;
+                    r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = ANYHIT ? d.w : 1e10f;
                     rng = __float_as_uint(d.w); rng0 = rng;
+                    blocked = false; candOverflow = false; candCount = 0;
                     lower.have = false;
                     best.valid = false; tlim = r.tmax; sp = 0;
                     bool finite = (r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z);
@@ -307,6 +327,12 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                         if (LDS_BVH) lbvh.tri(first + i, ta, tb, tc); else gbvh.tri(first + i, ta, tb, tc);
                         float t, u, v;
                         if (tri_test(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), r, sh, t, u, v)) {
+                            if (ANYHIT) {
+                                if (__float_as_uint(tc.w) & 1u) { blocked = true; break; }     // opaque instance: committed, whatever lies in front of it
+                                if (LDS_BVH) candidate_insert<kShadowCandidates>(lbvh, cand, candCount, candOverflow, t, first + i, __float_as_uint(ta.w), __float_as_uint(tb.w));
+                                else candidate_insert<kShadowCandidates>(gbvh, cand, candCount, candOverflow, t, first + i, __float_as_uint(ta.w), __float_as_uint(tb.w));
+                                continue;
+                            }
                             uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
                             bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
                             if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
@@ -316,10 +342,22 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                             }
                         }
                     }
-                    cur = (sp == 0) ? kTraversalDone : stack.pop(--sp);
+                    cur = (blocked || sp == 0) ? kTraversalDone : stack.pop(--sp);
                 }
                 // ---- traversal finished: candidate resolution (TraceRayStandard) and hit record
-                if (cur == kTraversalDone) {
+                if (ANYHIT) {
+                    if (cur == kTraversalDone) {
+                        const uint32_t id = a.b.sqId[slot];
+                        uint32_t code = blocked ? kVisBlocked : kVisClear;
+                        if (!blocked && candCount > 0) {
+                            uint2* out = a.b.sqCand + (size_t)id * kShadowCandidates;
+                            for (int k = 0; k < candCount; ++k) { float ct; uint32_t ctri; cand.key(k, ct, ctri); out[k] = make_uint2(__float_as_uint(ct), ctri); }
+                            code = kVisCandidates | ((uint32_t)candCount << 8) | (candOverflow ? 1u << 16 : 0u);
+                        }
+                        a.b.shVis[id] = code;
+                        active = false;
+                    }
+                } else if (cur == kTraversalDone) {
                     bool done = true;
                     if (best.valid && !best.opaque && !candidate_commits(s, best, rng)) {
                         // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
@@ -337,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             }
         }
     }
-    block_count_add(&a.counters->closestRays, 0, nRays);
+    if (!ANYHIT) block_count_add(&a.counters->closestRays, 0, nRays);      // shadow rays are counted by wf_shadow
 }
 
 // ------------------------------------------------------------------ shade (+ compaction, + NEE sample emission)
@@ -536,17 +574,67 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
     }
 }
 
+// ------------------------------------------------------------------ shadow rays (scenes with non-opaque geometry)
+// One ray per valid light sample of every shadow-queue entry, compacted per segment, for the any-hit pass of wf_extend<ANYHIT>.
+// nee_direction is evaluated here and again in wf_shadow (same inputs, same bits) rather than stored: 40 B per sample less traffic.
+template <bool DIRONLY>
+__global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTracerConstants cb)
+{
+    const SceneView& s = a.scene;
+    const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
+        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift, items = cnt * a.maxLights;
+        uint32_t outCount = 0;
+        for (uint32_t i0 = 0; i0 < items; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool valid = false; Ray ray; uint32_t id = 0;
+            if (i < items) {
+                const uint32_t el = i / a.maxLights, j = i - el * a.maxLights, e = segBase + el;
+                id = e * a.maxLights + j;
+                float4 h4 = a.b.sh4[e];
+                if (j < __float_as_uint(h4.w)) {
+                    float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], ls = a.b.shL[(size_t)e * a.maxLights + j];
+                    HrptGPULight l = load_light(s, __float_as_uint(ls.z));
+                    f3 L; float maxDist;
+                    if (nee_direction<DIRONLY>(l, mk3(h1.x, h1.y, h1.z), mk3(h0.x, h0.y, h0.z), sunDir, cb.m_CosSunAngularRadius, ls.x, ls.y, L, maxDist)) {
+                        ray = shadow_ray(mk3(h0.x, h0.y, h0.z), L, maxDist);
+                        valid = true;
+                    }
+                }
+                if (!valid) a.b.shVis[id] = kVisNoRay;
+            }
+            const unsigned long long m = __ballot(valid);
+            if (valid) {
+                const uint32_t o = segBase * a.maxLights + outCount + prefix_rank(m);
+                a.b.sqO[o] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tmin);
+                a.b.sqD[o] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.tmax);
+                a.b.sqId[o] = id;
+            }
+            outCount += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) a.b.sqCnt[seg] = outCount;
+    }
+}
+
 // ------------------------------------------------------------------ shadow (NEE visibility + accumulation)
-// NONOPAQUE: the scene has ForceNonOpaque instances -> per-lane candidate buffer in LDS (after the stack) and the buffered query
-template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, bool NONOPAQUE>
+// MODE kShadowOpaque: no ForceNonOpaque instance in the scene: plain any-hit query per light sample.
+// MODE kShadowBuffered: non-opaque geometry, the kernel traverses itself: per-lane candidate buffer in LDS (after the stack) and the buffered query.
+// MODE kShadowResolve: non-opaque geometry, visibility traversal already done by wf_shadow_rays + wf_extend<ANYHIT>: this kernel only walks
+//   the recorded candidate lists (its stack serves the rare re-trace behind an overflowing list) and evaluates the contributions.
+enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2 };
+template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE>
 __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
+    constexpr bool NONOPAQUE = MODE != kShadowOpaque;
+    constexpr int kLdsMax = MODE == kShadowResolve ? kExtendLdsStack : kShadowLdsStack;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStack<DEPTH, kShadowLdsStack> stack; LdsBvh<W> lbvh;
-    constexpr size_t candBytes = NONOPAQUE ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    LdsStack<DEPTH, kLdsMax> stack; LdsBvh<W> lbvh;
+    constexpr size_t candBytes = MODE == kShadowBuffered ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
-    if (DEPTH > kShadowLdsStack) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
-    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kShadowLdsStack>::kLds * kBlock * 4) + threadIdx.x;
+    if (DEPTH > kLdsMax) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kLdsMax>::kLds * kBlock * 4) + threadIdx.x;
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
@@ -562,12 +650,28 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                 uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 for (uint32_t j = 0; j < n; ++j) {
+                    uint32_t vis = kVisCandidates;
+                    if (MODE == kShadowResolve) {
+                        // outcome of the opaque any-hit pass (wf_shadow_rays + wf_extend<ANYHIT>): most rays are settled there
+                        vis = a.b.shVis[e * a.maxLights + j];
+                        if (vis == kVisNoRay) continue;                                  // nee_direction said no
+                        if (vis == kVisBlocked) { ++nRays; continue; }                   // shadow factor 0: contributes +0
+                    }
                     float4 ls = a.b.shL[(size_t)e * a.maxLights + j];
                     HrptGPULight l = load_light(s, __float_as_uint(ls.z));
                     f3 L; float maxDist;
                     if (!nee_direction<DIRONLY>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ls.x, ls.y, L, maxDist)) continue;
                     float shadow;
-                    if (NONOPAQUE) {
+                    if (MODE == kShadowResolve) {
+                        if (vis == kVisClear) shadow = 1.0f;                             // no triangle at all in (tmin, tmax)
+                        else {                                                           // the non-opaque triangles it crossed, nearest first
+                            Ray sr = shadow_ray(origin, L, maxDist);
+                            GlobalCandidates gc; gc.base = a.b.sqCand + (size_t)(e * a.maxLights + j) * kShadowCandidates;
+                            const int cnt = (int)((vis >> 8) & 0xFFu); const bool ovf = (vis >> 16) & 1u;
+                            if (LDS_BVH) shadow = shadow_resolve_candidates(s, lbvh, sr, make_shear(sr.d), cnt, ovf, gc, stack);
+                            else shadow = shadow_resolve_candidates(s, gbvh, sr, make_shear(sr.d), cnt, ovf, gc, stack);
+                        }
+                    } else if (MODE == kShadowBuffered) {
                         if (LDS_BVH) shadow = shadow_query_buffered<kShadowCandidates>(s, lbvh, origin, L, maxDist, stack, cand);
                         else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
                     } else {
@@ -656,25 +760,31 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 // ------------------------------------------------------------------ host side
 struct Variant { bool lds; int depth; int width; size_t ldsBytes; };
 
-template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity) { hipLaunchKernelGGL((wf_extend<L, D, W>), g, dim3(kBlock), sh, st, a, parity); }
-template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
+template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
-    if (nonOpaque) {   // general variant (all light types) + candidate buffer
-        hipLaunchKernelGGL((wf_shadow<L, D, W, false, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
-    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<L, D, W, false, false>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
+    else hipLaunchKernelGGL((wf_extend<L, D, W, false>), g, dim3(kBlock), sh, st, a, parity);
+}
+// nonOpaque: 0 = opaque scene, 1 = buffered query inside wf_shadow, 2 = resolve only (after the any-hit pass)
+template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
+{
+    if (nonOpaque == kShadowResolve) hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowResolve>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (nonOpaque == kShadowBuffered) {   // general variant (all light types) + candidate buffer
+        hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowBuffered>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
+    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
 // stack depths: BVH2 8/16/32 (needs maxDepth + 2), BVH4 16/32/64 (needs 3 * maxDepth4 + 2)
-template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
+template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
     if (v.width == 2) {
-        if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_t<L, 32, 2>(g, sh, st, a, parity); else launch_extend_t<L, 64, 2>(g, sh, st, a, parity);
+        if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity, anyHit); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity, anyHit); else if (v.depth <= 32) launch_extend_t<L, 32, 2>(g, sh, st, a, parity, anyHit); else launch_extend_t<L, 64, 2>(g, sh, st, a, parity, anyHit);
     } else {
-        if (v.depth <= 16) launch_extend_t<L, 16, 4>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_t<L, 32, 4>(g, sh, st, a, parity); else launch_extend_t<L, 64, 4>(g, sh, st, a, parity);
+        if (v.depth <= 16) launch_extend_t<L, 16, 4>(g, sh, st, a, parity, anyHit); else if (v.depth <= 32) launch_extend_t<L, 32, 4>(g, sh, st, a, parity, anyHit); else launch_extend_t<L, 64, 4>(g, sh, st, a, parity, anyHit);
     }
 }
-template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
+template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
     if (v.width == 2) {
         if (v.depth <= 8) launch_shadow_t<L, 8, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<L, 16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
@@ -682,11 +792,11 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
         if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     }
 }
-void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
+void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit = false)
 {
-    if (v.lds) launch_extend_l<true>(v, g, sh, st, a, parity); else launch_extend_l<false>(v, g, sh, st, a, parity);
+    if (v.lds) launch_extend_l<true>(v, g, sh, st, a, parity, anyHit); else launch_extend_l<false>(v, g, sh, st, a, parity, anyHit);
 }
-void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, bool nonOpaque)
+void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
     if (v.lds) launch_shadow_l<true>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_l<false>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
 }
@@ -777,6 +887,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16), oSh2 = carve(capacity * 16), oSh3 = carve(capacity * 16), oSh4 = carve(capacity * 16);
     size_t oShL = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
+    size_t oSqO = 0, oSqD = 0, oSqId = 0, oSqCnt = 0, oShVis = 0, oSqCand = 0;
+    if (traits.hasNonOpaque) {     // (the mode is picked below; the arrays are small next to the path queues)
+        oSqO = carve(capacity * 16 * maxLights); oSqD = carve(capacity * 16 * maxLights); oSqId = carve(capacity * 4 * maxLights);
+        oSqCnt = carve((size_t)segs * 4); oShVis = carve(capacity * 4 * maxLights); oSqCand = carve(capacity * 8 * kShadowCandidates * maxLights);
+    }
     if (off > st.poolBytes) {
         if (st.pool) { (void)hipStreamSynchronize(stream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
         e = hipMalloc(&st.pool, off);
@@ -795,6 +910,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1); a.b.sh2 = (float4*)(base + oSh2); a.b.sh3 = (float4*)(base + oSh3);
     a.b.sh4 = (float4*)(base + oSh4); a.b.shL = (float4*)(base + oShL);
     a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
+    a.b.sqO = (float4*)(base + oSqO); a.b.sqD = (float4*)(base + oSqD); a.b.sqId = (uint32_t*)(base + oSqId); a.b.sqCnt = (uint32_t*)(base + oSqCnt); a.b.shVis = (uint32_t*)(base + oShVis); a.b.sqCand = (uint2*)(base + oSqCand);
     a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
     a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
     a.counters = counters;
@@ -825,6 +941,15 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const Variant vE = pick(forced ? forced : 4, 0, kExtendLdsStack);
     Variant vS = pick(forced ? forced : 4, candBytes, kShadowLdsStack);
     if (!forced && vS.lds && !traits.hasNonOpaque) vS = pick(2, candBytes, kShadowLdsStack);
+    // Shadow rays of scenes with non-opaque geometry. Several lights per vertex or glass (rays that cross many non-opaque triangles) make
+    // per-ray cost very uneven: their visibility traversal runs in the refilling traversal kernel (wf_shadow_rays + wf_extend<ANYHIT>, which
+    // also records the crossed non-opaque triangles) and wf_shadow only resolves (glass config: 4.7 -> 4.2 ms per bounce, HRPT_WF_SHADOW_PATH).
+    // A single sun over alpha-tested foliage (config 4) is faster with wf_shadow's own buffered query (0.96 vs 1.07 ms per bounce).
+    int shadowMode = !traits.hasNonOpaque ? kShadowOpaque : ((maxLights > 1 || traits.hasTransmissiveOrBlend) ? kShadowResolve : kShadowBuffered);
+    if (traits.hasNonOpaque && st.shadowPath == 1) shadowMode = kShadowBuffered;
+    if (traits.hasNonOpaque && st.shadowPath == 2) shadowMode = kShadowResolve;
+    const Variant vA = pick(forced ? forced : 4, candBytes, kExtendLdsStack);     // any-hit pass over the shadow rays (same kernel family as vE)
+    if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
         // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part
@@ -881,6 +1006,16 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
                 st.forkEvents.push_back(f); st.joinEvents.push_back(j);
             }
         }
+        // NEE visibility + accumulation. With non-opaque geometry in the scene: ray generation, the opaque any-hit pass in the refilling
+        // traversal kernel, then wf_shadow for the contributions and the (few) rays that crossed non-opaque triangles.
+        auto shadow_stage = [&](hipStream_t sst, int bounce) {
+            if (shadowMode == kShadowResolve) {
+                if (traits.directionalLightsOnly) hipLaunchKernelGGL((wf_shadow_rays<true>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
+                else hipLaunchKernelGGL((wf_shadow_rays<false>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
+                launch_extend(vA, dim3(grid), vA.ldsBytes, sst, a, 0u, true);
+            }
+            launch_shadow(vS, dim3(grid), vS.ldsBytes, sst, a, cb, bounce, traits.directionalLightsOnly, shadowMode);
+        };
         bool pendingJoin = false;
         for (int bounce = 0; bounce < maxBounces; ++bounce) {
             const uint32_t parity = (uint32_t)bounce & 1u;
@@ -896,11 +1031,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
                 if ((e = hipEventRecord(st.forkEvents[(size_t)bounce], stream)) != hipSuccess || (e = hipStreamWaitEvent(st.auxStream, st.forkEvents[(size_t)bounce], 0)) != hipSuccess) { error = "fork to the shadow stream"; return e; }
-                launch_shadow(vS, dim3(grid), vS.ldsBytes, st.auxStream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+                shadow_stage(st.auxStream, bounce);
                 if ((e = hipEventRecord(st.joinEvents[(size_t)bounce], st.auxStream)) != hipSuccess) { error = "hipEventRecord(join)"; return e; }
                 pendingJoin = true;
             } else {
-                launch_shadow(vS, dim3(grid), vS.ldsBytes, stream, a, cb, bounce, traits.directionalLightsOnly, traits.hasNonOpaque);
+                shadow_stage(stream, bounce);
             }
             if (timed) timing_mark(st, stream, 2, false);
         }

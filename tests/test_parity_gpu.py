@@ -181,6 +181,40 @@ def test_forced_bvh_width(luts, width, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("path", [1, 2], ids=["buffered", "anyhit_resolve"])
+def test_forced_shadow_path(luts, path, monkeypatch):
+    """Scenes with non-opaque geometry take one of two shadow-ray schedules (HRPT_WF_SHADOW_PATH, read at hrpt_create): wf_shadow's own
+    buffered query, or ray generation + the any-hit pass of the refilling traversal kernel + candidate resolution. Both visit the
+    candidates in the same order, so both are bit-exact -- glass (many candidates per ray, media), alpha-tested foliage with textures,
+    stochastic BLEND, LDS-resident and global trees, more candidates than the per-ray buffer holds."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    monkeypatch.setenv("HRPT_WF_SHADOW_PATH", str(path))
+    c = PathTracerContext(0)
+    try:
+        sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=0.5, tex_size=32)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc = random_soup(luts, 600, 14, 0.5, 0.3, True)                      # small (LDS-resident) tree, BLEND + MASK + textures
+        view, pos = scenes.planar_view(96, 64, position=(0.2, 0.3, -5.0), aspect=1.5)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 64, 2, 8, S.FRAME_WAVEFRONT))
+        # a stack of 14 thin glass panes between the floor and the light: more non-opaque crossings than the 8-entry candidate buffer
+        b = scenes.SceneBuilder()
+        quad_v, quad_i = scenes.generate_floor_quad()
+        m = b.add_mesh(quad_v, quad_i)
+        floor = b.add_material(m_BaseColor=(0.8, 0.8, 0.8, 1))
+        glass = b.add_material(m_BaseColor=(0.9, 0.95, 1.0, 0.35), m_AlphaMode=S.ALPHA_MODE_BLEND)
+        b.add_instance(m, floor, scenes._mat(scale=(6, 1, 6)))
+        for k in range(14):
+            b.add_instance(m, glass, scenes._mat(scale=(3, 1, 3), translate=(0.0, 0.3 + 0.15 * k, 0.0)))
+        b.add_light(S.LIGHT_POINT, position=(0.3, 4.0, 0.2), intensity=40.0, range_=30.0, radius=0.1)
+        sc = b.finalize(luts)
+        view, pos = scenes.planar_view(64, 48, position=(0.0, 1.5, -6.0), pitch=0.15, aspect=64 / 48)
+        _assert_parity(*_run_both(c, sc, view, pos, 64, 48, 2, 6, S.FRAME_WAVEFRONT))
+    finally:
+        c.close()
+
+
 # ---- GPU-built acceleration structure (SURVEY.md 8f #4): same radiance bits as with the host SAH build ----------
 def _gpu_built(luts, sc, view, pos, w, h, spp, bounces, flags=S.FRAME_DEFAULT, builder=S.BVH_BUILDER_GPU_LBVH):
     from hobbyrenderer_amd.native import PathTracerContext
