@@ -86,6 +86,32 @@ def test_random_soup_all_material_classes(ctx, luts, flags, seed, blend, mask, t
     _assert_parity(*_run_both(ctx, sc, view, pos, 96, 64, 3, 8, flags))
 
 
+def test_random_material_subsets_wavefront_equals_megakernel_and_oracle(ctx, luts):
+    """The wavefront kernels are specialised on scene traits derived at upload (medium tracking, stochastic alpha, textures,
+    non-opaque geometry, light types, shadow-ray schedule). 48 random scenes over random SUBSETS of the material classes and light
+    sets vary those traits independently: the wavefront pipeline must equal the unspecialised megakernel bit for bit on all of them,
+    and the oracle on every fourth."""
+    from oracle.binding import Oracle
+    from scene_helpers import random_trait_scene
+    w, h, spp, bounces = 48, 32, 2, 6
+    view, pos = scenes.planar_view(w, h, position=(0.2, 0.3, -5.0), aspect=w / h)
+    for seed in range(48):
+        sc, classes, lights = random_trait_scene(luts, seed)
+        cb = scenes.fill_constants(view, pos, sc, 0, bounces)
+        ctx.upload_scene(sc); ctx.resize(w, h)
+        ctx.render(cb, accum_count=spp, flags=S.FRAME_MEGAKERNEL)
+        mk = ctx.read_accumulation()
+        ctx.resize(w, h)
+        ctx.render(cb, accum_count=spp, flags=S.FRAME_WAVEFRONT)
+        wf = ctx.read_accumulation()
+        assert np.array_equal(mk.view(np.uint32), wf.view(np.uint32)), f"seed {seed}: material classes {classes}, light set {lights}"
+        if seed % 4 == 0:
+            o = Oracle(sc)
+            oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), w, h, spp)
+            o.close()
+            assert np.array_equal(wf.view(np.uint32), oacc.view(np.uint32)), f"seed {seed} vs oracle: material classes {classes}, light set {lights}"
+
+
 def test_wavefront_equals_megakernel_full_config2(ctx, luts):
     """BASELINE config 2 at full size (1920x1080, 8 spp, 4 bounces): the oracle is too slow for the whole frame in a
     unit test, so the two independent GPU schedules (validation megakernel, wavefront pipeline) are compared bit for
