@@ -897,7 +897,6 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         e = hipMalloc(&st.pool, off);
         if (e != hipSuccess) { error = "hipMalloc(queue pool)"; return e; }
         st.poolBytes = off;
-        if (getenv("HRPT_DEBUG_POOL")) fprintf(stderr, "[hrpt] queue pool %p, %zu bytes\n", st.pool, off);
     }
     char* base = static_cast<char*>(st.pool);
     WfArgs a{};
