@@ -181,7 +181,10 @@ def main():
         views = [column_view(im, world, rank) if columns else im[y0:y1] for im in images]
         frames = PipelinedFrames([band_renderer(c) for c in lanes], views, H, W, rank, world, all_gather,
                                  lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), H * W, stream), dev,
-                                 lane_streams=lane_streams, layout="columns" if columns else "rows")
+                                 lane_streams=lane_streams, layout="columns" if columns else "rows",
+                                 # the step's product is the resolved image on every rank: shards -> Output in one pass, no assembled accumulation copy
+                                 resolve_columns=lambda sh, acc, out, stream: ctx.resolve_columns_device(sh.data_ptr(), acc.data_ptr() if acc is not None else 0, out.data_ptr(), W, H, world, stream),
+                                 keep_accumulation=False)
     step_no = [0]
 
     def step():

@@ -682,6 +682,18 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
     return HRPT_OK;
 }
 
+int hrpt_resolve_columns_device(HrptContext* c, const float* shardsDevice, float* accumulationDevice, float* outputDevice, uint32_t width, uint32_t height, uint32_t ranks, void* stream)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!shardsDevice || !outputDevice) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_columns_device: null image");
+    if (ranks == 0 || width == 0 || height == 0 || width % (8u * ranks) != 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_columns_device: width must be a positive multiple of 8 * ranks");
+    if ((uint64_t)width * height > 0xFFFFFFFFull) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_resolve_columns_device: image too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_resolve_columns(reinterpret_cast<const float4*>(shardsDevice), reinterpret_cast<float4*>(accumulationDevice), reinterpret_cast<float4*>(outputDevice),
+                                      width, height, ranks, static_cast<hipStream_t>(stream)));
+    return HRPT_OK;
+}
+
 int hrpt_set_bvh_builder(HrptContext* c, int builder)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

@@ -43,5 +43,6 @@ hipError_t launch_f16_table(float* out, hipStream_t stream);
 
 // Output[xy] = accum.rgb / accum.a (PathTracer.hlsl:339) over the whole image.
 hipError_t launch_resolve(const float4* accumulation, float4* output, uint32_t pixelCount, hipStream_t stream);
+hipError_t launch_resolve_columns(const float4* shards, float4* accumulation, float4* output, uint32_t width, uint32_t height, uint32_t ranks, hipStream_t stream);
 
 } // namespace hrt

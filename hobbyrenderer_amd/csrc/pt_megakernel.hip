@@ -99,6 +99,30 @@ __global__ void pt_resolve_kernel(const float4* __restrict__ accumulation, float
     }
 }
 
+// Column shards of `ranks` ranks, rank-major as an all-gather delivers them ([rank][y][column of the rank][8 pixels]), straight to the
+// resolved image (and, when asked for, the assembled accumulation image): one pass instead of re-assembly + resolve.
+__global__ void pt_resolve_columns_kernel(const float4* __restrict__ shards, float4* __restrict__ accumulation, float4* __restrict__ output,
+                                          uint32_t width, uint32_t height, uint32_t ranks)
+{
+    const uint32_t n = width * height, perRank = width / 8u / ranks;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t y = i / width, x = i - y * width, k = x >> 3, r = k % ranks, c = k / ranks;
+        float4 a = shards[(((size_t)r * height + y) * perRank + c) * 8u + (x & 7u)];
+        if (accumulation) accumulation[i] = a;
+        output[i] = make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f);
+    }
+}
+hipError_t launch_resolve_columns(const float4* shards, float4* accumulation, float4* output, uint32_t width, uint32_t height, uint32_t ranks, hipStream_t stream)
+{
+    if (width == 0 || height == 0) return hipSuccess;
+    uint32_t blocks = (width * height + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pt_resolve_columns_kernel, dim3(blocks), dim3(256), 0, stream, shards, accumulation, output, width, height, ranks);
+    return hipGetLastError();
+}
+
 hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstants& constants, float4* accumulation, float4* output,
                              uint32_t imageWidth, TileRect rect, DeviceCounters* counters, hipStream_t stream)
 {

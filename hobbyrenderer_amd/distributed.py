@@ -88,7 +88,8 @@ class PipelinedFrames:
     resolve(accum_tensor, out_tensor, stream_handle): Output = rgb / a (hrpt_resolve_device on GPUs).
     """
 
-    def __init__(self, render_band, band_view, height, width, rank, world, all_gather, resolve, device, lane_streams=None, layout="rows"):
+    def __init__(self, render_band, band_view, height, width, rank, world, all_gather, resolve, device, lane_streams=None, layout="rows",
+                 resolve_columns=None, keep_accumulation=True):
         import torch
         self.torch = torch
         self.render_band = list(render_band) if isinstance(render_band, (list, tuple)) else [render_band]
@@ -100,6 +101,9 @@ class PipelinedFrames:
             raise ValueError("one stream per lane")
         self.all_gather, self.resolve = all_gather, resolve
         self.rank, self.world = rank, world
+        # columns layout only: resolve_columns(shards, accumulation_or_None, output, stream_handle) fuses the re-assembly of the gathered
+        # shards with the resolve (hrpt_resolve_columns_device); keep_accumulation=False then skips the assembled accumulation image
+        self.resolve_columns, self.keep_accumulation = resolve_columns, keep_accumulation
         if layout not in ("rows", "columns"):
             raise ValueError("layout is 'rows' (contiguous row bands) or 'columns' (interleaved 8-pixel columns)")
         self.layout = layout
@@ -139,23 +143,25 @@ class PipelinedFrames:
                 self.rendered[s].record(main)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.rendered[s])
-                self._gather(s)
-                self.resolve(self.gathered[s], self.output[s], self.comm.cuda_stream)
+                self._gather_and_resolve(s, self.comm.cuda_stream)
                 self.delivered[s].record(self.comm)
         else:
             self.render_band[lane](self.y0, self.y1)
             self.staging[s].copy_(self.band_view[lane])
-            self._gather(s)
-            self.resolve(self.gathered[s], self.output[s], 0)
+            self._gather_and_resolve(s, 0)
         self.frame += 1
         return s
 
-    def _gather(self, s):
+    def _gather_and_resolve(self, s, stream_handle):
         if self.layout == "rows":
             self.all_gather(self.gathered[s], self.staging[s])
         else:
             self.all_gather(self.shards[s], self.staging[s])
+            if self.resolve_columns is not None:                                   # one fused pass: shards -> (accumulation,) output
+                self.resolve_columns(self.shards[s], self.gathered[s] if self.keep_accumulation else None, self.output[s], stream_handle)
+                return
             columns_to_image(self.shards[s], self.world, self.gathered[s])     # one 16 B/pixel pass on the comm stream
+        self.resolve(self.gathered[s], self.output[s], stream_handle)
 
     def finish(self):
         """Make the current stream wait for every submitted frame (host synchronisation stays with the caller)."""

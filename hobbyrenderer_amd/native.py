@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -49,6 +49,7 @@ lib.hrpt_read_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_write_accumulation.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_resolve_output.argtypes = [C.c_void_p]
 lib.hrpt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+lib.hrpt_resolve_columns_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
 lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -175,6 +176,11 @@ class PathTracerContext:
         """Output = accum.rgb / accum.a over caller-owned device images, asynchronously on `hip_stream` (integer handle)."""
         self._check(lib.hrpt_resolve_device(self._h, C.c_void_p(int(accumulation_ptr)), C.c_void_p(int(output_ptr)), int(pixel_count),
                                             C.c_void_p(int(hip_stream))))
+
+    def resolve_columns_device(self, shards_ptr, accumulation_ptr, output_ptr, width, height, ranks, hip_stream=0):
+        """Rank-major column shards -> Output (= rgb / a, image order) and, unless accumulation_ptr is 0/None, the assembled accumulation image."""
+        self._check(lib.hrpt_resolve_columns_device(self._h, C.c_void_p(int(shards_ptr)), C.c_void_p(int(accumulation_ptr or 0)) if accumulation_ptr else None,
+                                                    C.c_void_p(int(output_ptr)), int(width), int(height), int(ranks), C.c_void_p(int(hip_stream))))
 
     def trace_rays(self, rays, shadow=False):
         """rays: structured array of S.Ray; returns a structured array of S.RayHit (see hrpt_trace_rays)."""

@@ -348,6 +348,12 @@ int  hrpt_resolve_output(HrptContext* ctx);
  * gathered accumulation image that lives outside the context (pipelined multi-GPU frames, hobbyrenderer_amd/distributed.py).
  * Asynchronous; stream is a hipStream_t (NULL = the default stream). */
 int  hrpt_resolve_device(HrptContext* ctx, const float* accumulationDevice, float* outputDevice, uint64_t pixelCount, void* stream);
+/* The consumer of column-interleaved shards (HrptFrameParams::stripeCount): `shardsDevice` holds the all-gathered accumulation shards of
+ * `ranks` ranks, rank-major -- rank r's block is [height][width / 8 / ranks][8] float4, its k-th column being image column k * ranks + r.
+ * Writes Output = rgb / a in image order to outputDevice and, unless accumulationDevice is NULL, the re-assembled accumulation image:
+ * one pass over the data instead of re-assembly followed by hrpt_resolve_device. width must be a multiple of 8 * ranks. Asynchronous. */
+int  hrpt_resolve_columns_device(HrptContext* ctx, const float* shardsDevice, float* accumulationDevice, float* outputDevice,
+                                 uint32_t width, uint32_t height, uint32_t ranks, void* stream);
 
 /* ---- HDR post chain: the consumer of the pass -------------------------------------------------
  * HDRRenderer::Render (src/HDRRenderer.cpp:88-224) over Output (u0 = g_RG_HDRColor in path-tracer mode):

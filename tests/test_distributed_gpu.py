@@ -111,7 +111,8 @@ def test_device_tensor_view_and_rccl_allgather(luts):
         cviews = [column_view(device_tensor(c.device_images()[0], (72, 128, 4), dev), 1, 0) for c in lanes]
         frames = PipelinedFrames([lane_render_cols(c) for c in lanes], cviews, 72, 128, 0, 1, lambda f, b: dist.all_gather_into_tensor(f, b),
                                  lambda acc, out, stream: ctx.resolve_device(acc.data_ptr(), out.data_ptr(), 72 * 128, stream), dev, lane_streams=streams,
-                                 layout="columns")
+                                 layout="columns",
+                                 resolve_columns=lambda sh, acc, out, stream: ctx.resolve_columns_device(sh.data_ptr(), acc.data_ptr() if acc is not None else 0, out.data_ptr(), 128, 72, 1, stream))
         for f in range(3):
             count["n"] = f + 2
             slot = frames.submit()
@@ -160,6 +161,16 @@ def test_column_interleaved_shards_assemble_to_the_full_image(luts, flags):
     out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
     columns_to_image(torch.stack(shards).reshape(-1), n, out)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # the fused consumer (hrpt_resolve_columns_device): shards -> assembled accumulation + resolved output in one pass, or output only
+    stacked = torch.stack(shards).contiguous()
+    acc2 = torch.zeros((h, w, 4), dtype=torch.float32, device=dev); res2 = torch.zeros_like(acc2); res3 = torch.zeros_like(acc2)
+    ref.resolve_columns_device(stacked.data_ptr(), acc2.data_ptr(), res2.data_ptr(), w, h, n, torch.cuda.current_stream(dev).cuda_stream)
+    ref.resolve_columns_device(stacked.data_ptr(), 0, res3.data_ptr(), w, h, n, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(acc2.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(res2.cpu().numpy().view(np.uint32), ref.read_output().view(np.uint32)) and torch.equal(res2, res3)
+    with pytest.raises(HrptError, match="multiple of 8"):
+        ref.resolve_columns_device(stacked.data_ptr(), 0, res3.data_ptr(), w, h, 5, 0)
     with pytest.raises(HrptError, match="stripeIndex"):
         ref.render(cb, accum_count=1, stripes=(2, 2))
     with pytest.raises(ValueError):
