@@ -134,6 +134,27 @@ def test_wavefront_equals_megakernel_full_config2(ctx, luts):
     assert np.array_equal(wf[500:564].view(np.uint32), oacc[500:564].view(np.uint32))
 
 
+@pytest.mark.parametrize("config", [4, 5])
+def test_wavefront_equals_megakernel_full_size_configs_4_and_5(ctx, luts, config):
+    """BASELINE configs 4 and 5 (stand-in scenes) at 1920x1080 with their own bounce counts (8 / 12), 2 accumulation indices: the
+    oracle is far too slow at this size, so the specialised wavefront pipeline (GPU-built tree for config 4, shadow-ray stage with the
+    any-hit pass for config 5, overflow stacks) is compared bit for bit with the unspecialised one-thread-per-pixel megakernel, and
+    the ray counters must agree."""
+    sc, view, pos, cfg = (scenes.config_sponza_class if config == 4 else scenes.config_glass)(luts, 1920, 1080)
+    ctx.upload_scene(sc); ctx.resize(1920, 1080)
+    cb = scenes.fill_constants(view, pos, sc, 0, cfg["max_bounces"])
+    ctx.reset_stats()
+    ctx.render(cb, accum_count=2, flags=S.FRAME_MEGAKERNEL)
+    mk = ctx.read_accumulation(); st_mk = ctx.stats()
+    ctx.resize(1920, 1080)
+    ctx.reset_stats()
+    ctx.render(cb, accum_count=2, flags=S.FRAME_DEFAULT)
+    wf = ctx.read_accumulation(); st_wf = ctx.stats()
+    assert np.array_equal(mk.view(np.uint32), wf.view(np.uint32))
+    assert (st_mk.closestRays, st_mk.shadowRays) == (st_wf.closestRays, st_wf.shadowRays) and st_wf.closestRays > 4_000_000
+    assert (wf[..., 3] == 2).all() and np.isfinite(wf).all()
+
+
 def test_progressive_resume_and_tiles(ctx, luts):
     """first_accum_index + existing accumulation (resume) and tile rectangles give the same image as one call."""
     sc, view, pos, cfg = scenes.config_cornell(luts, 128, 72)
