@@ -51,6 +51,7 @@ struct BuildBuffers {
     float4* pMin; float4* pMax; uint32_t* pSize; uint32_t* pParent; uint32_t* pL; uint32_t* pR;
     uint32_t* clusterA; uint32_t* clusterB; uint32_t* nn; uint32_t* mergeFlag; uint32_t* validFlag; uint32_t* mergeIdx; uint32_t* validIdx;
     uint32_t* finalPos;
+    uint32_t* plocState;        // [0] clusters left, [1] merged nodes created so far, [2] error flag
     // outputs
     GpuNode* nodes; GpuNode4* nodes4; GpuTri* tris; GpuTriAttr* attrs; GpuTriTangent* tangents;
 };
@@ -241,8 +242,11 @@ __global__ __launch_bounds__(kB) void k_ploc_init(BuildBuffers b)
     b.pMin[k] = b.boxMinU[g]; b.pMax[k] = b.boxMaxU[g]; b.pSize[k] = 1u; b.pParent[k] = 0xFFFFFFFFu;
     b.clusterA[k] = k;
 }
-__global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* __restrict__ cluster, uint32_t count)
+// The iteration state lives on the device (plocState: [0] clusters left, [1] nodes created, [2] error), so that a batch of iterations runs
+// without a host round trip; grids and scan lengths use the cluster count of the batch's start (an upper bound inside the batch).
+__global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* __restrict__ cluster)
 {
+    const uint32_t count = b.plocState[0];
     uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= count) return;
     uint32_t me = cluster[i];
@@ -257,17 +261,19 @@ __global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* 
     }
     b.nn[i] = bestJ;
 }
-__global__ __launch_bounds__(kB) void k_ploc_flags(BuildBuffers b, uint32_t count)
+__global__ __launch_bounds__(kB) void k_ploc_flags(BuildBuffers b, uint32_t bound)
 {
+    const uint32_t count = b.plocState[0];
     uint32_t i = blockIdx.x * kB + threadIdx.x;
-    if (i >= count) return;
+    if (i >= count) { if (i < bound) { b.mergeFlag[i] = 0u; b.validFlag[i] = 0u; } return; }      // the scans run over `bound` entries
     uint32_t j = b.nn[i];
     bool mutual = j != i && b.nn[j] == i;
     b.mergeFlag[i] = (mutual && i < j) ? 1u : 0u;
     b.validFlag[i] = (mutual && i > j) ? 0u : 1u;
 }
-__global__ __launch_bounds__(kB) void k_ploc_apply(BuildBuffers b, const uint32_t* __restrict__ cluster, uint32_t* __restrict__ clusterOut, uint32_t count, uint32_t created)
+__global__ __launch_bounds__(kB) void k_ploc_apply(BuildBuffers b, const uint32_t* __restrict__ cluster, uint32_t* __restrict__ clusterOut)
 {
+    const uint32_t count = b.plocState[0], created = b.plocState[1];
     uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= count || !b.validFlag[i]) return;
     uint32_t pos = b.validIdx[i], me = cluster[i];
@@ -281,6 +287,14 @@ __global__ __launch_bounds__(kB) void k_ploc_apply(BuildBuffers b, const uint32_
         b.pParent[me] = id; b.pParent[other] = id;
         clusterOut[pos] = id;
     } else clusterOut[pos] = me;
+}
+__global__ void k_ploc_advance(BuildBuffers b)
+{
+    const uint32_t count = b.plocState[0];
+    if (count <= 1u) return;                                           // finished: the remaining iterations of the batch are no-ops
+    const uint32_t merges = b.mergeIdx[count - 1u] + b.mergeFlag[count - 1u];
+    if (merges == 0u || merges >= count) { b.plocState[2] = 1u; b.plocState[0] = 1u; return; }   // cannot happen with mutual nearest neighbours; never loop forever
+    b.plocState[0] = count - merges; b.plocState[1] += merges;
 }
 // position of the first primitive of every pool node in depth-first order (left subtree first): sum of the left siblings' sizes on the way up
 __global__ __launch_bounds__(kB) void k_ploc_offsets(BuildBuffers b)
@@ -577,7 +591,7 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
         A.off = 0;
         b.triU = A.take<GpuTri>(n); b.boxMinU = A.take<float4>(n); b.boxMaxU = A.take<float4>(n);
         b.keyA = A.take<uint64_t>(n); b.keyB = A.take<uint64_t>(n); b.valA = A.take<uint32_t>(n); b.valB = A.take<uint32_t>(n);
-        b.sceneBounds = A.take<uint32_t>(8); b.flags = A.take<uint32_t>(8);
+        b.sceneBounds = A.take<uint32_t>(8); b.flags = A.take<uint32_t>(8); b.plocState = A.take<uint32_t>(8);
         b.childL = A.take<uint32_t>(n); b.childR = A.take<uint32_t>(n); b.rangeFirst = A.take<uint32_t>(n); b.rangeLast = A.take<uint32_t>(n);
         b.parentOfInternal = A.take<uint32_t>(n); b.parentOfLeaf = A.take<uint32_t>(n); b.visit = A.take<uint32_t>(n);
         b.nodeMin = A.take<float4>(n); b.nodeMax = A.take<float4>(n);
@@ -647,21 +661,27 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
             if (!usePloc) continue;
             hipLaunchKernelGGL(k_ploc_init, gT, blk, 0, stream, b);
             uint32_t count = n, created = 0; uint32_t* cur = b.clusterA; uint32_t* nxt = b.clusterB; bool ok = true;
-            while (count > 1) {
-                const dim3 gC((count + kB - 1) / kB);
-                hipLaunchKernelGGL(k_ploc_nn, gC, blk, 0, stream, b, cur, count);
-                hipLaunchKernelGGL(k_ploc_flags, gC, blk, 0, stream, b, count);
-                if ((e = rocprim::exclusive_scan(prim, scanBytes, b.mergeFlag, b.mergeIdx, 0u, count, rocprim::plus<uint32_t>(), stream)) != hipSuccess ||
-                    (e = rocprim::exclusive_scan(prim, scanBytes, b.validFlag, b.validIdx, 0u, count, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(PLOC)");
-                hipLaunchKernelGGL(k_ploc_apply, gC, blk, 0, stream, b, cur, nxt, count, created);
-                uint32_t tail[2] = { 0, 0 };
-                if ((e = hipMemcpyAsync(&tail[0], b.mergeIdx + (count - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
-                    (e = hipMemcpyAsync(&tail[1], b.mergeFlag + (count - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
-                    (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (PLOC iteration)");
-                const uint32_t merges = tail[0] + tail[1];
-                if (merges == 0 || merges >= count) { ok = false; break; }      // cannot happen with mutual nearest neighbours; never loop forever
-                created += merges; count -= merges; std::swap(cur, nxt);
+            const uint32_t init[4] = { n, 0u, 0u, 0u };
+            if ((e = hipMemcpyAsync(b.plocState, init, sizeof init, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e, "GPU BVH build (PLOC state)");
+            for (int batch = 0; count > 1 && ok && batch < 64; ++batch) {
+                const uint32_t bound = count;                          // no cluster list of this batch is longer
+                const dim3 gC((bound + kB - 1) / kB);
+                for (int it = 0; it < 6; ++it) {
+                    hipLaunchKernelGGL(k_ploc_nn, gC, blk, 0, stream, b, cur);
+                    hipLaunchKernelGGL(k_ploc_flags, gC, blk, 0, stream, b, bound);
+                    if ((e = rocprim::exclusive_scan(prim, scanBytes, b.mergeFlag, b.mergeIdx, 0u, bound, rocprim::plus<uint32_t>(), stream)) != hipSuccess ||
+                        (e = rocprim::exclusive_scan(prim, scanBytes, b.validFlag, b.validIdx, 0u, bound, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(PLOC)");
+                    hipLaunchKernelGGL(k_ploc_apply, gC, blk, 0, stream, b, cur, nxt);
+                    hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(1), 0, stream, b);
+                    std::swap(cur, nxt);
+                }
+                uint32_t state[3] = { 0, 0, 0 };
+                if ((e = hipMemcpyAsync(state, b.plocState, sizeof state, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+                    (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH build (PLOC batch)");
+                if (state[2] || state[0] == 0 || state[0] > count) { ok = false; break; }
+                count = state[0]; created = state[1];
             }
+            if (count > 1) ok = false;
             if (!ok || created != n - 1) continue;
             hipLaunchKernelGGL(k_ploc_offsets, dim3((2 * n - 1 + kB - 1) / kB), blk, 0, stream, b);
             hipLaunchKernelGGL(k_ploc_finish, dim3((2 * n - 1 + kB - 1) / kB), blk, 0, stream, b, b.valA);

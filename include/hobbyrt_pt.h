@@ -271,7 +271,7 @@ int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output
  * triangles) or on the GPU (Morton-order LBVH or PLOC clustering: milliseconds). Radiance is identical either way (the hit
  * definition is BVH-independent). The GPU builders fall back to the host one for scenes under 8 triangles or when their
  * tree is deeper than the traversal stacks allow. The default, HRPT_BVH_BUILDER_AUTO, takes the host builder below 65 536
- * triangles and PLOC above (measured on MI355X: same frame time as the SAH tree at 101 k and 1.17 M triangles, 3 ms / 6 ms
+ * triangles and PLOC above (measured on MI355X: same frame time as the SAH tree at 101 k and 1.17 M triangles, 2 ms / 5 ms
  * instead of 32 ms / 548 ms of build time; on small scenes the SAH tree still renders up to 20 % faster). */
 #define HRPT_BVH_BUILDER_HOST_SAH 0
 #define HRPT_BVH_BUILDER_GPU_LBVH 1      /* Morton radix tree (Karras 2012): fastest build */
