@@ -209,6 +209,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # setup, not a step: every lane (context) renders once so that its queue pool is allocated and its kernels are loaded whatever W is
+    for _ in range(len(lanes)):
+        step()
+    sync_all()
     for _ in range(args.warmup):
         step()
     sync_all()
