@@ -231,6 +231,16 @@ def main():
     st = _Sum
     if lane_streams is not None:
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # reference point outside the timed region: the same steps one frame at a time (lane 0 only, frames back to back on one stream)
+    one_at_a_time_ms = None
+    if not sharded and len(lanes) > 1:
+        n1 = max(2, min(args.steps, 10))
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            ctx.render(cb, accum_count=spp, flags=flags)
+        ctx.synchronize()
+        one_at_a_time_ms = (time.perf_counter() - t1) / n1 * 1e3
     # per-kernel-class device times: a few extra steps with HRPT_FRAME_PROFILE (events around every launch), outside the timed region
     prof_steps = 0
     if args.mode != "megakernel":
@@ -261,6 +271,7 @@ def main():
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
                        "sharding": (f"{world} rank(s), 8-pixel columns interleaved (column k on rank k mod {world}), BVH+scene replicated" if columns else f"{world} row band(s) of {rows} rows, BVH+scene replicated") + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
                        "frames_in_flight": len(lanes),
+                       **({"ms_per_step_one_frame_in_flight": one_at_a_time_ms} if one_at_a_time_ms is not None else {}),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
         }
