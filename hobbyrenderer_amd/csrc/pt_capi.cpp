@@ -788,6 +788,21 @@ int hrpt_selftest_f16_decode(HrptContext* c, float* out65536)
     return HRPT_OK;
 }
 
+int hrpt_selftest_unorm8(HrptContext* c, float* out512)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!out512) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_selftest_unorm8: null out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, 512 * sizeof(float)));
+    hipError_t e = launch_unorm8_table(d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out512, d, 512 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, HRPT_ERR_HIP, std::string("hrpt_selftest_unorm8: ") + hipGetErrorString(e));
+    return HRPT_OK;
+}
+
 int hrpt_reset_stats(HrptContext* c)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

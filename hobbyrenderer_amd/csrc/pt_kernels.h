@@ -39,6 +39,7 @@ hipError_t launch_post_chain(const float4* hdr, float4* display, uint32_t pixelC
 hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRayHit* hits, uint64_t count, bool shadow, hipStream_t stream);
 
 // Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).
+hipError_t launch_unorm8_table(float* out512, hipStream_t stream);
 hipError_t launch_f16_table(float* out, hipStream_t stream);
 
 // Output[xy] = accum.rgb / accum.a (PathTracer.hlsl:339) over the whole image.

@@ -137,6 +137,16 @@ __global__ void pt_f16_table_kernel(float* __restrict__ out)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 65536u) out[i] = half_bits_to_float(i);
 }
+__global__ void pt_unorm8_table_kernel(float* __restrict__ out)
+{
+    uint32_t i = threadIdx.x;
+    if (i < 256u) { out[i] = unorm8_to_float(i); out[256u + i] = (float)i / 255.0f; }      // fast path, and the division it replaces
+}
+hipError_t launch_unorm8_table(float* out512, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_unorm8_table_kernel, dim3(1), dim3(256), 0, stream, out512);
+    return hipGetLastError();
+}
 hipError_t launch_f16_table(float* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(pt_f16_table_kernel, dim3(256), dim3(256), 0, stream, out);

@@ -380,6 +380,8 @@ int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray
 int  hrpt_reset_stats(HrptContext* ctx);
 /* Device self-test: out65536[i] = the kernels' decode of the binary16 bit pattern i (RGBA16F LUT texels). */
 int  hrpt_selftest_f16_decode(HrptContext* ctx, float* out65536);
+/* out512[i] = the kernels' RGBA8_UNORM channel decode of byte i (i < 256); out512[256 + i] = (float)i / 255.0f computed on the device. */
+int  hrpt_selftest_unorm8(HrptContext* ctx, float* out512);
 
 /* Host-side helpers of PathTracerRenderer::Render, exported so that callers in other languages
  * produce the same constants: Halton (src/Utilities.cpp:67-79) and the CB fill (:58-75). */

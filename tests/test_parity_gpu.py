@@ -397,3 +397,12 @@ def test_device_f16_decode_table(ctx):
     ref = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
     nan = np.isnan(ref)
     assert np.array_equal(got.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]) and np.isnan(got[nan]).all()
+
+
+def test_device_unorm8_table(ctx):
+    """RGBA8_UNORM channels are decoded without the IEEE division sequence (one Newton step with FMAs): for all 256 bytes the result must
+    equal byte / 255.0f as the device's own correctly rounded division and as numpy compute it."""
+    fast, div = ctx.selftest_unorm8()
+    ref = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    assert np.array_equal(fast.view(np.uint32), div.view(np.uint32))
+    assert np.array_equal(fast.view(np.uint32), ref.view(np.uint32))
