@@ -888,7 +888,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     size_t oShL = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
     size_t oSqO = 0, oSqD = 0, oSqId = 0, oSqCnt = 0, oShVis = 0, oSqCand = 0;
-    if (traits.hasNonOpaque) {     // (the mode is picked below; the arrays are small next to the path queues)
+    if (traits.hasNonOpaque || maxLights > 1) {     // (the mode is picked below; the arrays are small next to the path queues)
         oSqO = carve(capacity * 16 * maxLights); oSqD = carve(capacity * 16 * maxLights); oSqId = carve(capacity * 4 * maxLights);
         oSqCnt = carve((size_t)segs * 4); oShVis = carve(capacity * 4 * maxLights); oSqCand = carve(capacity * 8 * kShadowCandidates * maxLights);
     }
@@ -940,13 +940,17 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const Variant vE = pick(forced ? forced : 4, 0, kExtendLdsStack);
     Variant vS = pick(forced ? forced : 4, candBytes, kShadowLdsStack);
     if (!forced && vS.lds && !traits.hasNonOpaque) vS = pick(2, candBytes, kShadowLdsStack);
-    // Shadow rays of scenes with non-opaque geometry. Several lights per vertex or glass (rays that cross many non-opaque triangles) make
-    // per-ray cost very uneven: their visibility traversal runs in the refilling traversal kernel (wf_shadow_rays + wf_extend<ANYHIT>, which
-    // also records the crossed non-opaque triangles) and wf_shadow only resolves (glass config: 4.7 -> 4.2 ms per bounce, HRPT_WF_SHADOW_PATH).
-    // A single sun over alpha-tested foliage (config 4) is faster with wf_shadow's own buffered query (0.96 vs 1.07 ms per bounce).
-    int shadowMode = !traits.hasNonOpaque ? kShadowOpaque : ((maxLights > 1 || traits.hasTransmissiveOrBlend) ? kShadowResolve : kShadowBuffered);
-    if (traits.hasNonOpaque && st.shadowPath == 1) shadowMode = kShadowBuffered;
-    if (traits.hasNonOpaque && st.shadowPath == 2) shadowMode = kShadowResolve;
+    // Shadow-ray schedule. Several lights per vertex, or glass (rays that cross many non-opaque triangles), make the per-ray cost very
+    // uneven; when the tree is in global memory their visibility traversal runs in the refilling traversal kernel (wf_shadow_rays +
+    // wf_extend<ANYHIT>, which also records the crossed non-opaque triangles) and wf_shadow only resolves: glass config 4.7 -> 4.2 ms per
+    // bounce, an opaque 101 k-triangle scene with three lights 20.3 -> 18.4 ms per frame. With an LDS-resident tree the traversal is too
+    // cheap to pay for the extra passes (Cornell box with three lights 11.3 vs 13.1 ms), and a single sun over alpha-tested foliage
+    // (config 4) is faster with wf_shadow's own buffered query (0.96 vs 1.07 ms per bounce). HRPT_WF_SHADOW_PATH = 1 / 2 forces either.
+    const bool unevenRays = maxLights > 1 || (traits.hasNonOpaque && traits.hasTransmissiveOrBlend);
+    const int selfMode = traits.hasNonOpaque ? kShadowBuffered : kShadowOpaque;
+    int shadowMode = (!vS.lds && unevenRays) ? kShadowResolve : selfMode;
+    if (st.shadowPath == 1) shadowMode = selfMode;
+    if (st.shadowPath == 2 && (traits.hasNonOpaque || maxLights > 1)) shadowMode = kShadowResolve;
     const Variant vA = pick(forced ? forced : 4, candBytes, kExtendLdsStack);     // any-hit pass over the shadow rays (same kernel family as vE)
     if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)

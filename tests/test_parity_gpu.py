@@ -242,6 +242,8 @@ def test_forced_shadow_path(luts, path, monkeypatch):
         _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
         sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=0.5, tex_size=32)
         _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54, extra_lights=True)   # all opaque, three lights: any-hit pass without candidates
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, 5, S.FRAME_WAVEFRONT))
         sc = random_soup(luts, 600, 14, 0.5, 0.3, True)                      # small (LDS-resident) tree, BLEND + MASK + textures
         view, pos = scenes.planar_view(96, 64, position=(0.2, 0.3, -5.0), aspect=1.5)
         _assert_parity(*_run_both(c, sc, view, pos, 96, 64, 2, 8, S.FRAME_WAVEFRONT))
