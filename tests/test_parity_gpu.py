@@ -88,14 +88,15 @@ def test_random_soup_all_material_classes(ctx, luts, flags, seed, blend, mask, t
 
 def test_random_material_subsets_wavefront_equals_megakernel_and_oracle(ctx, luts):
     """The wavefront kernels are specialised on scene traits derived at upload (medium tracking, stochastic alpha, textures,
-    non-opaque geometry, light types, shadow-ray schedule). 48 random scenes over random SUBSETS of the material classes and light
+    non-opaque geometry, light types, shadow-ray schedule). 48 random scenes (HRPT_TEST_TRAIT_SEEDS for more) over random SUBSETS of the material classes and light
     sets vary those traits independently: the wavefront pipeline must equal the unspecialised megakernel bit for bit on all of them,
     and the oracle on every fourth."""
     from oracle.binding import Oracle
     from scene_helpers import random_trait_scene
     w, h, spp, bounces = 48, 32, 2, 6
     view, pos = scenes.planar_view(w, h, position=(0.2, 0.3, -5.0), aspect=w / h)
-    for seed in range(48):
+    import os
+    for seed in range(int(os.environ.get("HRPT_TEST_TRAIT_SEEDS", "48"))):
         sc, classes, lights = random_trait_scene(luts, seed)
         cb = scenes.fill_constants(view, pos, sc, 0, bounces)
         ctx.upload_scene(sc); ctx.resize(w, h)
