@@ -228,6 +228,7 @@ def main():
     class _Sum:                                               # ray counters of all lanes of this rank
         closestRays = sum(int(c.stats().closestRays) for c in lanes)
         shadowRays = sum(int(c.stats().shadowRays) for c in lanes)
+        lastRenderMs = float(ctx.stats().lastRenderMs)
     st = _Sum
     if lane_streams is not None:
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -336,6 +337,8 @@ def main():
                               "whole_step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
                               "n_closest": n_c, "t_closest": t_c, "n_shadow": n_s, "t_shadow": t_s}
         print(json.dumps(result))
+    for c in lanes[1:]:
+        c.close()
     ctx.close()
     if sharded:
         dist.destroy_process_group()
