@@ -97,7 +97,7 @@ def test_random_material_subsets_wavefront_equals_megakernel_and_oracle(ctx, lut
     view, pos = scenes.planar_view(w, h, position=(0.2, 0.3, -5.0), aspect=w / h)
     import os
     for seed in range(int(os.environ.get("HRPT_TEST_TRAIT_SEEDS", "48"))):
-        sc, classes, lights = random_trait_scene(luts, seed)
+        sc, classes, lights = random_trait_scene(luts, seed, int(os.environ.get("HRPT_TEST_TRAIT_TRIS", "160")))   # 3000+: tree in global memory
         cb = scenes.fill_constants(view, pos, sc, 0, bounces)
         ctx.upload_scene(sc); ctx.resize(w, h)
         ctx.render(cb, accum_count=spp, flags=S.FRAME_MEGAKERNEL)
