@@ -330,6 +330,9 @@ def main():
             kernel_times = None
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "note": "achieved = SURVEY 8(d) algorithmic bytes / measured launch time; a fraction above 1 means those bytes (BVH nodes, triangles, "
+                                      "attribute records) are served from LDS and L2, not HBM: 'traffic' is the HBM traffic the PMC counters saw per launch, "
+                                      "'valu' shows what actually bounds the kernel (VALU issue)",
                               "traffic": _pmc_traffic(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None,
                               "valu": _pmc_valu(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None, "kernel": kernel, "kernels": kernel_times, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                               "algorithmic_bytes_per_launch": per_launch_bytes,
