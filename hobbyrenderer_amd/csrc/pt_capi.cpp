@@ -694,6 +694,13 @@ int hrpt_resolve_columns_device(HrptContext* c, const float* shardsDevice, float
     return HRPT_OK;
 }
 
+int hrpt_set_shadow_overlap(HrptContext* c, int enabled)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    c->wf.serialShadow = enabled == 0;
+    return HRPT_OK;
+}
+
 int hrpt_set_bvh_builder(HrptContext* c, int builder)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

@@ -376,6 +376,12 @@ int  hrpt_read_display(HrptContext* ctx, float* rgba, size_t bytes);           /
 int  hrpt_get_exposure(HrptContext* ctx, float* exposure, uint32_t histogram256[256]);   /* histogram may be NULL */
 int  hrpt_set_exposure(HrptContext* ctx, float exposure);                      /* the persistent exposure buffer, initially 1 */
 
+/* Intra-frame overlap: by default the shadow stage of bounce b runs on a second, library-owned stream next to the traversal of bounce
+ * b + 1 (they share no buffer). That fills the tails of a context that renders one frame at a time (-3 % per frame). A host that keeps
+ * two frames in flight on two contexts already fills those tails with the other frame; there the fork / join events only cost
+ * (-5 % per frame with the overlap off at full size, -13 % for an eighth of the picture): pass 0. Takes effect at the next hrpt_render. */
+int  hrpt_set_shadow_overlap(HrptContext* ctx, int enabled);
+
 int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray counters are cumulative */
 int  hrpt_reset_stats(HrptContext* ctx);
 /* Device self-test: out65536[i] = the kernels' decode of the binary16 bit pattern i (RGBA16F LUT texels). */

@@ -15,7 +15,7 @@ sc, view, pos, cfg = scenes.config_cornell(luts, W, H)
 cb = scenes.fill_constants(view, pos, sc, 0, 4)
 lanes = []
 for k in range(2):
-    c = native.PathTracerContext(0); c.upload_scene(sc); c.resize(W, H); lanes.append(c)
+    c = native.PathTracerContext(0); c.upload_scene(sc); c.resize(W, H); c.set_shadow_overlap(False); lanes.append(c)
 streams = [torch.cuda.Stream(dev) for _ in lanes]
 for c, st in zip(lanes, streams): c.set_stream(st.cuda_stream)
 def bare(frames=200):

@@ -10,7 +10,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 135
 y0 = min(405, 1080 - rows); tile = (0, y0, 1920, y0 + rows)
 ctxs = []
 for k in range(3):
-    c = native.PathTracerContext(0); c.upload_scene(sc); c.resize(1920, 1080); ctxs.append(c)
+    c = native.PathTracerContext(0); c.upload_scene(sc); c.resize(1920, 1080); c.set_shadow_overlap(not os.environ.get('NO_OVERLAP')); ctxs.append(c)
 def run(lanes, frames=40):
     for c in ctxs[:lanes]: c.render(cb, accum_count=8, tile=tile)
     for c in ctxs[:lanes]: c.synchronize()
