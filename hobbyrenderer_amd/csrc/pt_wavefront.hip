@@ -775,7 +775,8 @@ template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStrea
     else hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
-// stack depths: BVH2 8/16/32 (needs maxDepth + 2), BVH4 16/32/64 (needs 3 * maxDepth4 + 2)
+// stack need classes: BVH2 8/16/32/64 (maxDepth + 2), BVH4 16/32/64 (3 * maxDepth4 + 2); class 64 = "deeper than the LDS part": the kernel keeps
+// kExtendLdsStack / kShadowLdsStack entries in LDS and the rest in the overflow columns (LdsStack)
 template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
     if (v.width == 2) {

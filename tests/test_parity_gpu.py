@@ -197,7 +197,7 @@ def test_error_paths(ctx, luts):
 # ---- BASELINE configs 4 and 5 (stand-in scenes) at sizes the oracle finishes in seconds ---------
 @pytest.mark.parametrize("flags", [S.FRAME_MEGAKERNEL, S.FRAME_DEFAULT], ids=["megakernel", "default"])
 def test_config4_sponza_class_reduced(ctx, luts, flags):
-    """~100 k world triangles (BVH in HBM/L2, 32-deep LDS stack), textured PBR + MASK foliage + emissive, open sky."""
+    """~100 k world triangles (GPU-built tree in HBM/L2, LDS stack + overflow columns), textured PBR + MASK foliage + emissive, open sky."""
     sc, view, pos, cfg = scenes.config_sponza_class(luts, 160, 90, detail=1.0, tex_size=64)
     res = _run_both(ctx, sc, view, pos, 160, 90, 2, cfg["max_bounces"], flags)
     assert res[2].bvhTriangleCount > 90000
