@@ -85,8 +85,18 @@ def _pipelined_worker(rank, world, port, w, h, bounces, out_dir, lanes=1, layout
     y0, y1 = band_for_rank(h, world, rank)
     fulls = [torch.from_numpy(a) for a in accs]
     views = [column_view(f, world, rank) if layout == "columns" else f[y0:y1] for f in fulls]
+    fused = {}
+    if layout == "columns":     # the fused consumer (hrpt_resolve_columns_device on GPUs): shards -> output, plus the assembled image on request
+        from hobbyrenderer_amd.distributed import columns_to_image
+
+        def resolve_columns(shards, acc_out, out_img, stream):
+            img = columns_to_image(shards, world, torch.empty((h, w, 4)))
+            if acc_out is not None:
+                acc_out.copy_(img)
+            out_img.copy_(img / img[..., 3:4])
+        fused = dict(resolve_columns=resolve_columns, keep_accumulation=True)
     frames = PipelinedFrames([band_renderer(a) for a in accs], views, h, w, rank, world,
-                             lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"), layout=layout)
+                             lambda f, b: dist.all_gather_into_tensor(f, b), resolve, torch.device("cpu"), layout=layout, **fused)
     for f in range(3):
         state["first"] = f
         slot = frames.submit()
