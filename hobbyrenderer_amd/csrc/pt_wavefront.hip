@@ -978,7 +978,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         // small (tile-sharded multi-GPU runs) and balance uneven per-entry work (several lights per shadow entry). Measured on MI355X
         // (scripts/sweep_env.sh, scripts/seg_sweep.py): 512 wins for full-frame single-light batches (-3 % config 2, -4 % config 4),
         // 256 for a 135-row band (0.76 vs 0.89 ms) and for the three-light glass scene.
-        const bool largeBatch = a.numSamples >= (8u << 20) && maxLights == 1;
+        // (512 only with an LDS-resident tree: rays through a big tree in global memory differ too much in length -- 256 is 2..4 % faster
+        // there: config 4 14.4 -> 14.2 ms, 1.17 M triangles 20.1 -> 19.4 ms)
+        const bool largeBatch = a.numSamples >= (8u << 20) && maxLights == 1 && vE.lds;
         uint32_t shift = st.segmentShift ? st.segmentShift : (largeBatch ? 9u : 8u);
         if (shift < 6) shift = 6;
         if (shift > 10) shift = 10;
