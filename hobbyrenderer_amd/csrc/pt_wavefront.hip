@@ -954,7 +954,10 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     if (st.shadowPath == 2 && (traits.hasNonOpaque || maxLights > 1)) shadowMode = kShadowResolve;
     const Variant vA = pick(forced ? forced : 4, candBytes, kExtendLdsStack);     // any-hit pass over the shadow rays (same kernel family as vE)
     if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
-    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;   // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py)
+    // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py). A context that is one lane of a
+    // two-frames-in-flight loop (hrpt_set_shadow_overlap(ctx, 0)) and traverses a tree in global memory does better with half the grid:
+    // its latency-bound kernels leave room for the other lane's (config 4 14.4 -> 14.0 ms, config 5 22.6 -> 21.9 ms per frame).
+    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : ((st.serialShadow && !vE.lds) ? 8 : 16);
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
         // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part
         const uint32_t worst = vE.width == 4 || vS.width == 4 ? 3 * traits.bvh4MaxDepth + 2 : traits.bvhMaxDepth + 2;
