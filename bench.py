@@ -4,15 +4,21 @@ procedural scene) on N MI355X of one node.
 
 A "step" is one full render of that frame through the C ABI (hrpt_render with accumCount = spp) with the
 Scene, BVH and LUTs already resident in HBM. N > 1: one process per GPU (torch.distributed over RCCL), the
-image is sharded by row bands (pixels are independent: RNG.hlsli:21-27), scene replicated, one all-gather of
-the RGBA32F accumulation bands per step, then the resolve (Output = accum.rgb / accum.a). Total work is fixed
+image is sharded over the ranks (pixels are independent: RNG.hlsli:21-27), scene replicated, one all-gather of
+the RGBA32F accumulation shards per step, then the resolve (Output = accum.rgb / accum.a). Total work is fixed
 as N grows ("strong" scaling); value is the whole-job aggregate.
 
 Rays = closest-hit queries + shadow queries actually launched (device counters; identical to the oracle's).
-roofline: algorithmic bytes per ray from SURVEY.md 8(d) -- B_closest = 768 + 32 n + 48 t, B_shadow = 36 + 32 n
-+ 48 t, + 48 B per pixel per spp -- with n (AABB tests) and t (triangle tests) counted by the CPU oracle on a
-bounded sample of the same workload, divided by the dominant kernel's device time (HIP events recorded by the
-library on its own stream). cpu_baseline: the oracle (a port; the reference has no CPU path) timed on the host.
+
+roofline (HBM, 8 TB/s): `achieved` = the bytes the dominant kernel class actually streams through its queues per launch
+(records read / written x record size, from counters the kernels keep during the run: HrptStats::*QueueBytes) divided by
+its average launch duration (HIP events the library records on ITS stream around every launch, in a separate
+HRPT_FRAME_PROFILE pass of the same frame); `frac` = achieved / peak, always <= 1. `algorithmic_model` keeps SURVEY.md
+8(d)'s per-ray figure (B_closest = 768 + 32 n + 48 t, B_shadow = 36 + 32 n + 48 t, + 48 B per pixel per spp, n / t counted
+by the CPU oracle on this very config): it prices BVH-node, triangle and attribute touches as memory traffic although LDS /
+L2 serve them, so it can exceed the peak and bounds nothing on small scenes. `traffic` (PMC FETCH_SIZE / WRITE_SIZE) and
+`valu` (instruction-issue counters) come from committed rocprofv3 passes of this command and name their source file.
+cpu_baseline: the oracle (a port; the reference has no CPU path) timed on all host cores of the box.
 """
 import argparse
 import json
@@ -29,32 +35,39 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under
-    profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM), or None."""
+def _pmc_file(kind, config):
+    """Newest committed rocprofv3 --pmc summary of `kind` ('traffic' | 'valu') for this config, or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_config{config}.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            return json.load(f), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
-def _pmc_valu(kernel):
-    """VALU-issue counters of `kernel` on config 2 from the committed rocprofv3 --pmc passes (profiles/r*_pmc_valu_config2.json):
-    the kernels of this path are VALU-issue-bound, so these say more about them than the HBM fraction does."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_config2.json")))
-    if not files:
-        return None
+def _host_cores():
+    """(threads to use, cores visible): every core this process may run on, bounded by the cgroup CPU quota of the box when one is set
+    (a one-GPU box exposes all 256 hardware threads of the host in its affinity mask but schedules a 16-core share: 256 oracle threads
+    on that share measured 24 Mrays/s against 41 with 16)."""
+    visible = len(os.sched_getaffinity(0))
+    quota = None
     try:
-        with open(files[-1]) as f:
-            return json.load(f).get(kernel)
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = max(1, int(round(int(q) / int(period))))
     except (OSError, ValueError):
-        return None
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, int(round(q / period)))
+        except (OSError, ValueError):
+            pass
+    return (min(visible, quota) if quota else visible), visible
 
 
 def _baseline_metric():
@@ -73,8 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=8)
-    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--spp", type=int, default=None, help="default: BASELINE.json's value for the config (8 / 8 / 64 for configs 2 / 4 / 5)")
+    ap.add_argument("--bounces", type=int, default=None, help="default: BASELINE.json's value for the config (4 / 8 / 12)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (default: every core this process may run on)")
     ap.add_argument("--mode", choices=["default", "megakernel", "wavefront"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -119,7 +133,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
+    base_spp, base_bounces = {2: (8, 4), 4: (8, 8), 5: (64, 12)}[args.config]      # BASELINE.json configs[1] / [3] / [4]
+    W, H = args.width, args.height
+    spp = args.spp if args.spp is not None else base_spp
+    bounces = args.bounces if args.bounces is not None else base_bounces
     luts = native.precompute_atmosphere()
     if args.config == 2:
         sc, view, pos, _ = scenes.config_cornell(luts, W, H)
@@ -269,6 +286,7 @@ def main():
         pst = ctx.stats()
 
     red_dev = torch.device("cpu") if rehearse else dev
+    my_elapsed = elapsed
     tm = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     rays = torch.tensor([float(st.closestRays + st.shadowRays), float(st.closestRays), float(st.shadowRays)], dtype=torch.float64, device=red_dev)
     if sharded:
@@ -276,6 +294,16 @@ def main():
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tm.item())
     total_rays, closest_total, shadow_total = (float(x) for x in rays.tolist())
+
+    # per-rank breakdown for the sharded runs (the first hardware SCALE run should explain itself): render time of this rank's share
+    # alone (HRPT_FRAME_PROFILE pass above, lastRenderMs = device time of one hrpt_render) and what the gather pipeline adds per step
+    per_rank = None
+    if sharded:
+        mine = torch.tensor([float(pst.lastRenderMs) if prof_steps else 0.0, my_elapsed / args.steps * 1e3,
+                             frames.gather_ms() if frames is not None else 0.0], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "render_ms_alone": float(t[0]), "step_ms": float(t[1]), "gather_resolve_ms": float(t[2])} for i, t in enumerate(allr)]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -286,20 +314,27 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not rehearse else "REHEARSAL on one GPU (gloo through host): not a result",
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
+                       "baseline_config": args.config, "baseline_parameters": (spp, bounces) == (base_spp, base_bounces) and (W, H) == (1920, 1080),
                        "sharding": (f"{world} rank(s), 8-pixel columns interleaved (column k on rank k mod {world}), BVH+scene replicated" if columns else f"{world} row band(s) of {rows} rows, BVH+scene replicated") + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
                        "frames_in_flight": len(lanes),
-                       **({"ms_per_step_one_frame_in_flight": one_at_a_time_ms} if one_at_a_time_ms is not None else {}),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
         }
-        # ---- cpu_baseline + n/t counters: oracle on a bounded sample (N=1 only; other N reuse the constants below)
-        n_c = t_c = n_s = t_s = None
+        if one_at_a_time_ms is not None:
+            # the reference drains the GPU every frame (src/Renderer.cpp:2053): the same steps with ONE frame in flight, a first-class figure
+            result["one_frame_in_flight"] = {"ms_per_step": one_at_a_time_ms, "value": total_rays / args.steps / one_at_a_time_ms / 1e3, "unit": "Mrays/s"}
+        if per_rank is not None:
+            result["per_rank"] = per_rank
+        # ---- cpu_baseline + n/t counters: the oracle on a bounded sample of THIS config (N = 1 only)
+        model = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.binding import Oracle, OrStats
             o = Oracle(sc)
             ost = OrStats()
-            cores = min(16, len(os.sched_getaffinity(0)))   # the CPU share of a one-GPU box
-            sample_spp = spp                                 # the whole workload: ~10 s of CPU work on 16 cores
+            cores, visible = _host_cores()                              # every host core this process may use; both counts are reported
+            cores = args.cpu_cores or cores
+            # bounded sample: whole frames of the same workload, fewer accumulation indices when the full job would take minutes
+            sample_spp = spp if args.config != 5 else min(spp, 8)
             t1 = time.perf_counter()
             o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), W, H, sample_spp, nthreads=cores, stats=ost)
             cpu_s = time.perf_counter() - t1
@@ -308,53 +343,70 @@ def main():
             n_c, t_c = d["closestNodes"] / max(1, d["closestRays"]), d["closestTris"] / max(1, d["closestRays"])
             n_s, t_s = d["shadowNodes"] / max(1, d["shadowRays"]), d["shadowTris"] / max(1, d["shadowRays"])
             result["cpu_baseline"] = {
-                "value": (d["closestRays"] + d["shadowRays"]) / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "value": (d["closestRays"] + d["shadowRays"]) / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "host_threads_visible": visible, "kind": "port",
                 "sample": f"oracle (CPU restatement of the reference shader; the reference has no CPU path), same scene, {W}x{H}, "
-                          f"accumulation indices 0..{sample_spp - 1} ({sample_spp} of {spp} spp), {bounces} bounces, {cores} pthreads, {cpu_s:.2f} s"}
-        if n_c is None:
-            # constants measured by the oracle on config 2 (Measurement); used when the oracle leg is skipped
-            n_c, t_c, n_s, t_s = 16.14, 2.60, 17.37, 2.71
-        b_closest = 768.0 + 32.0 * n_c + 48.0 * t_c
-        b_shadow = 36.0 + 32.0 * n_s + 48.0 * t_s
-        r0_closest, r0_shadow = float(st.closestRays) / args.steps, float(st.shadowRays) / args.steps   # rank 0, per step
-        px0 = (W * H // world if columns else (y1 - y0) * W) if sharded else W * H
-        step_bytes = r0_closest * b_closest + r0_shadow * b_shadow + px0 * spp * 48.0
+                          f"accumulation indices 0..{sample_spp - 1} ({sample_spp} of {spp} spp), {bounces} bounces, {cores} pthreads "
+                          f"(the box's CPU share: min(affinity mask = {visible}, cgroup quota)), {cpu_s:.2f} s"}
+            b_closest = 768.0 + 32.0 * n_c + 48.0 * t_c
+            b_shadow = 36.0 + 32.0 * n_s + 48.0 * t_s
+            px0 = W * H
+            step_bytes = closest_total / args.steps * b_closest + shadow_total / args.steps * b_shadow + px0 * spp * 48.0
+            model = {"source": "SURVEY.md 8(d) byte model with n / t counted by the oracle on this config in this run; prices LDS- and L2-served "
+                               "BVH / attribute touches as memory traffic, so it is an upper bound on useful traffic, not a roofline",
+                     "n_closest": n_c, "t_closest": t_c, "n_shadow": n_s, "t_shadow": t_s,
+                     "bytes_per_closest_ray": b_closest, "bytes_per_shadow_ray": b_shadow, "bytes_per_step": step_bytes,
+                     "whole_step_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9}
         if prof_steps and pst.traceKernelLaunches > 0:
-            # wavefront: per-class device time from HIP events the library records on ITS stream around every launch.
-            # SURVEY 8(d) bytes split by the kernel that touches them (the three classes sum to B_closest / B_shadow):
-            #   wf_extend: ray record 32 + traversal 32n+48t + hit record 20 per closest ray
-            #   wf_shade : shading gather 588 + path state 128 per closest ray (+ 48 B/pixel/spp lives in raygen/resolve)
-            #   wf_shadow: 36 + 32n+48t per shadow ray
+            # wavefront: per-class device time (HIP events on the library's stream around every launch) and the queue bytes the class
+            # moved in the same profiled steps (counters kept by the kernels; record sizes in pt_wavefront.hip, wavefront_queue_bytes)
             classes = {
-                "wf_extend": (pst.traceKernelMs, pst.traceKernelLaunches, r0_closest * (52.0 + 32.0 * n_c + 48.0 * t_c)),
-                "wf_shade": (pst.shadeKernelMs, pst.shadeKernelLaunches, r0_closest * (588.0 + 128.0)),
-                "wf_shadow": (pst.shadowKernelMs, pst.shadowKernelLaunches, r0_shadow * b_shadow),
+                "wf_raygen": (pst.raygenKernelMs, pst.raygenKernelLaunches, pst.raygenQueueBytes),
+                "wf_extend": (pst.traceKernelMs, pst.traceKernelLaunches, pst.traceQueueBytes),
+                "wf_shade": (pst.shadeKernelMs, pst.shadeKernelLaunches, pst.shadeQueueBytes),
+                "wf_shadow": (pst.shadowKernelMs, pst.shadowKernelLaunches, pst.shadowQueueBytes),
+                "wf_resolve": (pst.resolveKernelMs, pst.resolveKernelLaunches, pst.resolveQueueBytes),
             }
             kernel = max(classes, key=lambda k: classes[k][0])
-            tot_ms, n_launch, bytes_per_step = classes[kernel]
+            tot_ms, n_launch, qbytes = classes[kernel]
             launches = n_launch / prof_steps
-            per_launch_bytes = bytes_per_step / launches
-            avg_ms = tot_ms / n_launch
-            kernel_times = {k: {"ms_per_step": v[0] / prof_steps, "launches_per_step": v[1] / prof_steps,
-                                "algorithmic_GBps": v[2] / (v[0] / prof_steps * 1e-3) / 1e9} for k, v in classes.items()}
+            per_launch_bytes = qbytes / max(1, n_launch)
+            avg_ms = tot_ms / max(1, n_launch)
+            kernel_times = {k: {"ms_per_step": v[0] / prof_steps, "launches_per_step": v[1] / prof_steps, "queue_bytes_per_step": v[2] / prof_steps,
+                                "queue_GBps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else None),
+                                "frac_of_hbm_peak": (v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if v[0] > 0 else None)} for k, v in classes.items()}
+            all_ms = sum(v[0] for v in classes.values()); all_bytes = sum(v[2] for v in classes.values())
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            traffic_doc, traffic_src = _pmc_file("traffic", args.config)
+            valu_doc, valu_src = _pmc_file("valu", args.config)
+            at_baseline = world == 1 and (W, H, spp, bounces) == (1920, 1080, base_spp, base_bounces)
+            # config 5's counters were collected at 8 of its 64 spp (per-launch figures do not depend on the spp count beyond the batch size)
+            traffic = (traffic_doc or {}).get(kernel, {}).get("hbm_bytes_per_launch") if at_baseline else None
+            result["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "kernel": kernel, "avg_launch_ms": avg_ms, "launches_per_step": launches, "queue_bytes_per_launch": per_launch_bytes,
+                "achieved_source": "in-run: HrptStats queue bytes (records read / written x record size, counted by the kernels) / HIP-event launch time",
+                "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 "
+                                                        "correction; committed file, not measured in this run)") if traffic is not None else None,
+                "whole_step": {"queue_bytes": all_bytes / prof_steps, "kernel_ms": all_ms / prof_steps,
+                               "queue_GBps": all_bytes / (all_ms * 1e-3) / 1e9, "frac": all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "bytes_per_sample": all_bytes / prof_steps / (W * H * spp / world)},
+                "kernels": kernel_times,
+                "valu": ({**valu_doc.get(kernel, {}), "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"}
+                         if (valu_doc and at_baseline) else None),
+                "algorithmic_model": model,
+                "queue_pool_bytes": int(pst.queuePoolBytes),
+                "note": "frac = queue bytes the dominant kernel class streams per launch / its launch time / 8 TB/s. The traversal kernel is not HBM-bound: "
+                        "its BVH is LDS- or L2-resident and it is limited by VALU / LDS issue and lane utilisation (see 'valu'); 'whole_step' is the figure "
+                        "for all kernel classes of a frame together.",
+            }
         else:
-            # megakernel: one launch per accumulation index does the whole dispatch
-            launches = spp
-            per_launch_bytes = step_bytes / spp
+            # megakernel: one launch per accumulation index does the whole dispatch; its HBM traffic is the 48 B per pixel of the image streams
             avg_ms = st.lastRenderMs / spp
-            kernel = "pt_megakernel"
-            kernel_times = None
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "note": "achieved = SURVEY 8(d) algorithmic bytes / measured launch time; a fraction above 1 means those bytes (BVH nodes, triangles, "
-                                      "attribute records) are served from LDS and L2, not HBM: 'traffic' is the HBM traffic the PMC counters saw per launch, "
-                                      "'valu' shows what actually bounds the kernel (VALU issue)",
-                              "traffic": _pmc_traffic(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None,
-                              "valu": _pmc_valu(kernel) if (args.config == 2 and world == 1 and (W, H, spp, bounces) == (1920, 1080, 8, 4)) else None, "kernel": kernel, "kernels": kernel_times, "avg_launch_ms": avg_ms, "launches_per_step": launches,
-                              "algorithmic_bytes_per_launch": per_launch_bytes,
-                              "bytes_per_closest_ray": b_closest, "bytes_per_shadow_ray": b_shadow,
-                              "whole_step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
-                              "n_closest": n_c, "t_closest": t_c, "n_shadow": n_s, "t_shadow": t_s}
+            per_launch_bytes = W * H * 48.0 / world
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "kernel": "pt_megakernel", "avg_launch_ms": avg_ms, "launches_per_step": spp, "traffic": None,
+                                  "algorithmic_model": model}
         print(json.dumps(result))
     for c in lanes[1:]:
         c.close()

@@ -48,6 +48,7 @@ struct HrptContext {
     WavefrontState wf;
     SceneTraits traits;
     int bvhBuilder = HRPT_BVH_BUILDER_AUTO;       // hrpt_set_bvh_builder
+    uint32_t megakernelFallbacks = 0;             // renders that wanted the wavefront pipeline but could not use it (HrptStats)
     HrptBuildInfo buildInfo{};
 };
 
@@ -484,6 +485,7 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipSetDevice(c->device));
 
     bool wavefront = (p->flags & HRPT_FRAME_MEGAKERNEL) == 0 && wavefront_supports(c->view, p->constants);
+    if (!wavefront && (p->flags & HRPT_FRAME_MEGAKERNEL) == 0) c->megakernelFallbacks++;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (wavefront) {
         std::string werr;
@@ -727,12 +729,25 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     DeviceCounters h[kCounterShards];
     HIP_TRY(c, hipMemcpy(h, c->dCounters, sizeof h, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
-    for (int i = 0; i < kCounterShards; ++i) { out->closestRays += h[i].closestRays; out->shadowRays += h[i].shadowRays; out->paths += h[i].paths; }
+    DeviceCounters total{};
+    for (int i = 0; i < kCounterShards; ++i) {
+        total.closestRays += h[i].closestRays; total.shadowRays += h[i].shadowRays; total.paths += h[i].paths; total.neeEntries += h[i].neeEntries;
+        total.neeSamples += h[i].neeSamples; total.radianceShade += h[i].radianceShade; total.radianceShadow += h[i].radianceShadow;
+    }
+    out->closestRays = total.closestRays; out->shadowRays = total.shadowRays; out->paths = total.paths;
+    out->neeEntries = total.neeEntries; out->neeSamples = total.neeSamples;
+    out->megakernelFallbacks = c->megakernelFallbacks; out->queuePoolBytes = c->wf.poolBytes;
+    if (total.neeEntries || c->wf.raygenBytes) {     // the wavefront pipeline ran since the last reset
+        wavefront_queue_bytes(c->wf, total, out->traceQueueBytes, out->shadeQueueBytes, out->shadowQueueBytes);
+        out->raygenQueueBytes = c->wf.raygenBytes; out->resolveQueueBytes = c->wf.resolveBytes;
+    }
     if (c->timed) { float ms = 0.0f; if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess) out->lastRenderMs = ms; }
     wavefront_collect_timing(c->wf);
     out->traceKernelMs = c->wf.kernelMs[0]; out->traceKernelLaunches = c->wf.kernelLaunches[0];
     out->shadeKernelMs = c->wf.kernelMs[1]; out->shadeKernelLaunches = c->wf.kernelLaunches[1];
     out->shadowKernelMs = c->wf.kernelMs[2]; out->shadowKernelLaunches = c->wf.kernelLaunches[2];
+    out->raygenKernelMs = c->wf.kernelMs[3]; out->raygenKernelLaunches = c->wf.kernelLaunches[3];
+    out->resolveKernelMs = c->wf.kernelMs[4]; out->resolveKernelLaunches = c->wf.kernelLaunches[4];
     out->bvhNodeCount = c->bvhNodes; out->bvhTriangleCount = c->bvhTris; out->bvhMaxDepth = c->traits.bvhMaxDepth;
     return HRPT_OK;
 }
@@ -817,6 +832,7 @@ int hrpt_reset_stats(HrptContext* c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(DeviceCounters) * kCounterShards, c->stream));
     wavefront_reset_timing(c->wf);
+    c->megakernelFallbacks = 0;
     return HRPT_OK;
 }
 

@@ -11,10 +11,14 @@ namespace hrt {
 struct SceneView;   // pt_device.h
 
 constexpr int kCounterShards = 32;   // DeviceCounters[kCounterShards] per context; a block adds to shard blockIdx % kCounterShards
-struct DeviceCounters {         // 32 B; summed over the shards by hrpt_get_stats
-    unsigned long long closestRays;
-    unsigned long long shadowRays;
-    unsigned long long paths;
+struct DeviceCounters {         // 64 B; summed over the shards by hrpt_get_stats. The wavefront kernels address the fields by word index.
+    unsigned long long closestRays;       // 0
+    unsigned long long shadowRays;        // 1
+    unsigned long long paths;             // 2
+    unsigned long long neeEntries;        // 3: shadow-queue entries wf_shade wrote (path vertices with at least one light sample)
+    unsigned long long neeSamples;        // 4: light-sample records wf_shadow read
+    unsigned long long radianceShade;     // 5: sampleRadiance read-modify-writes of wf_shade (emissive / sky terms)
+    unsigned long long radianceShadow;    // 6: sampleRadiance read-modify-writes of wf_shadow (NEE terms)
     unsigned long long pad;
 };
 

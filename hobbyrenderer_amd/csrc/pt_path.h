@@ -24,6 +24,7 @@ struct PathState {
 // what shade_surface_a needs to keep for shade_surface_b
 struct SurfaceCarry {
     f3 N, V, worldPos, baseColor, F0; float Fr, roughness, metallic, ior;
+    uint32_t rngBeforeLights;      // RNG state at the top of the light loop (:260): lets a schedule replay the loop's draws
 };
 
 HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_t px, uint32_t py)
@@ -391,7 +392,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
                 refractedDir = normalize(refractedDir);
                 float alpha = pbr.roughness * pbr.roughness, alpha2 = alpha * alpha;
                 float NdotL_t = hrt_abs(dot(N, refractedDir));
-                float G1_t = (NdotL_t > 1e-5f) ? 2.0f * NdotL_t / (NdotL_t + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL_t * NdotL_t)) : 0.0f;
+                float G1_t = (NdotL_t > HRT_K_EPSILON) ? 2.0f * NdotL_t / (NdotL_t + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL_t * NdotL_t)) : 0.0f;
                 bsdfWeight = ((pbr.baseColor * (1.0f - F_mf)) * G1_t) * NdotL_t;
             }
             ps.throughput = ps.throughput * bsdfWeight;
@@ -410,6 +411,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
 
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;
     carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic; carry.ior = mat.m_IOR;
+    carry.rngBeforeLights = ps.rng;
     for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
         HrptGPULight l = load_light(s, i);
         float ux, uy;

@@ -34,8 +34,13 @@ struct WavefrontState {
     std::vector<hipEvent_t> events;
     std::vector<uint8_t> kind;
     uint32_t eventsUsed = 0;
-    float kernelMs[3] = { 0.0f, 0.0f, 0.0f };      // summed device time per kernel class since the last reset
-    uint32_t kernelLaunches[3] = { 0, 0, 0 };
+    // kernel classes: 0 extend, 1 shade, 2 shadow stage, 3 raygen, 4 resolve
+    float kernelMs[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };      // summed device time per kernel class since the last reset
+    uint32_t kernelLaunches[5] = { 0, 0, 0, 0, 0 };
+    // queue-byte accounting (HrptStats::*QueueBytes): what the host knows per render is summed here, the rest follows from the device
+    // counters and the record layout of the last render
+    uint64_t raygenBytes = 0, resolveBytes = 0;
+    struct Layout { uint32_t pathRecordBytes = 48, maxLights = 1; int shadowMode = 0; } layout;
     // tuning knobs (0 = default)
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
@@ -61,5 +66,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
 void wavefront_release(WavefrontState& st);
 void wavefront_collect_timing(WavefrontState& st);   // call after the stream is synchronised; folds pending events into kernelMs
 void wavefront_reset_timing(WavefrontState& st);
+// Queue bytes per kernel class from the device counters (summed over the shards) and the record layout of the last render.
+void wavefront_queue_bytes(const WavefrontState& st, const DeviceCounters& total, uint64_t& trace, uint64_t& shade, uint64_t& shadow);
 
 } // namespace hrt

@@ -180,6 +180,20 @@ HRT_DEV void block_count_add(unsigned long long* counterField0, size_t fieldOffs
         if (t) atomicAdd(counterField0 + (size_t)(blockIdx.x % kCounterShards) * (sizeof(DeviceCounters) / 8) + fieldOffsetWords, t);
     }
 }
+// The same for N wave-uniform counts (each wave passes its own totals; fields = word indices into DeviceCounters).
+template <int N>
+HRT_DEV void block_count_add_uniform(DeviceCounters* counters, const int (&fields)[N], const unsigned int (&perWave)[N])
+{
+    __shared__ unsigned int partialU[N][kBlock / 64];
+    if (lane_id() == 0)
+        for (int k = 0; k < N; ++k) partialU[k][threadIdx.x >> 6] = perWave[k];
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)N) {
+        unsigned long long t = 0;
+        for (uint32_t i = 0; i < kBlock / 64; ++i) t += partialU[threadIdx.x][i];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(counters + blockIdx.x % kCounterShards) + fields[threadIdx.x], t);
+    }
+}
 
 // ------------------------------------------------------------------ raygen
 __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerConstants cb, JitterTable jt)
@@ -386,8 +400,12 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 // compile the corresponding branches out (the general variant is always correct).
 // Occupancy: the multi-light variant is forced to 4 waves per SIMD (28 B of scratch per lane; -9 % on the glass config); the single-light
 // variants stay at 3 (forcing 4 costs them +3 %: 44..108 B of spills on a kernel that is already latency-bound).
+// MAXL = 0: any number of lights. The light loop runs twice: once to draw (it fixes the RNG state and tells whether the vertex has any light
+// sample at all, which the compaction needs), and -- for the lanes that have one -- again from the saved RNG state, writing the samples
+// straight into the entry's slots instead of buffering them per lane (AccumulateDirectLighting loops over all m_LightCount lights,
+// CommonLighting.hlsli:877-908; the reference's UI does not bound them).
 template <int MAXL, bool SIMPLE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1 ? 4 : 3, MAXL > 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 1 ? 4 : 3, MAXL != 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
     constexpr uint32_t kRing = 128, kRingFields = 23;
     float* const ring = reinterpret_cast<float*>(shadeSmem) + (size_t)(threadIdx.x >> 6) * kRing * kRingFields;
     uint32_t ringHead = 0, pending = 0;
+    unsigned int nEntriesOut = 0, nRadiance = 0;      // wave-uniform statistics (HrptStats queue-byte accounting)
     // The wave works through its segments (gw, gw + totalWaves, ...) as one stream of 64-lane iterations: when the open segment A
     // has fewer than 64 entries left, the remaining lanes take the first entries of the next non-empty segment B, so only the wave's
     // last iteration is partially filled (after compaction a 256-slot segment holds ~207 / 168 / 136 paths at bounces 1 / 2 / 3: one
@@ -436,11 +455,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
             }
             const bool inA = lane < takeA;
             uint32_t outCountB = 0, shCountB = 0;
-            bool valid = lane < takeA + takeB, alive = false, wantDefer = false;
+            bool valid = lane < takeA + takeB, alive = false, wantDefer = false, wantRadiance = false;
             LobeDraw ld; ld.spec = false; ld.specProb = 0.0f; ld.root = 0.0f; ld.sp = 0.0f; ld.cp = 0.0f;
             uint32_t nNee = 0, smp = 0;
             PathState ps; f3 neeT = mk3(0.0f, 0.0f, 0.0f);
-            NeeBuf<MAXL> nee; SurfaceCarry carry;
+            constexpr bool STREAMED = MAXL == 0;
+            NeeBuf<(STREAMED ? 1 : MAXL)> nee; SurfaceCarry carry;
             if (valid) {
                 uint32_t slot = inA ? baseA + nextA + lane : baseB + (lane - takeA);
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
@@ -458,7 +478,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
                     Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
                     SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t li, float ux, float uy) {
-                        if (nNee < (uint32_t)MAXL) { nee.ux[nNee] = ux; nee.uy[nNee] = uy; nee.light[nNee] = li; ++nNee; }
+                        if (STREAMED) ++nNee;
+                        else if (nNee < (uint32_t)MAXL) { nee.ux[nNee] = ux; nee.uy[nNee] = uy; nee.light[nNee] = li; ++nNee; }
                     });
                     if (oc == SURFACE_TRANSMITTED) alive = true;
                     else {
@@ -487,7 +508,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
                     a.b.radiance[smp] = r;
                 }
                 if (lastBounce) alive = false;
+                wantRadiance = addRadiance;
             }
+            nRadiance += (unsigned int)__popcll(__ballot(wantRadiance));
             // ---- wave-local compaction of survivors into the out queue of their own segment
             const unsigned long long mA = __ballot(alive && inA), mB = __ballot(alive && !inA);
             if (alive) {
@@ -509,12 +532,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
                 a.b.sh2[e] = make_float4(carry.V.x, carry.V.y, carry.V.z, carry.metallic);
                 a.b.sh3[e] = make_float4(carry.baseColor.x, carry.baseColor.y, carry.baseColor.z, carry.ior);
                 a.b.sh4[e] = make_float4(neeT.x, neeT.y, neeT.z, __uint_as_float(nNee));
+                if (STREAMED) {
+                    const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
+                    uint32_t rng = carry.rngBeforeLights, j = 0;
+                    for (uint32_t i = 0; i < cb.m_LightCount; ++i) {
+                        HrptGPULight l = load_light(s, i);
+                        float ux, uy;
+                        if (nee_draw<false>(l, carry.N, carry.worldPos, sunDir, rng, ux, uy)) a.b.shL[(size_t)e * a.maxLights + j++] = make_float4(ux, uy, __uint_as_float(i), 0.0f);
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < MAXL; ++j)
-                    if ((uint32_t)j < nNee) a.b.shL[(size_t)e * a.maxLights + j] = make_float4(nee.ux[j], nee.uy[j], __uint_as_float(nee.light[j]), 0.0f);
+                    for (int j = 0; j < (STREAMED ? 1 : MAXL); ++j)
+                        if ((uint32_t)j < nNee) a.b.shL[(size_t)e * a.maxLights + j] = make_float4(nee.ux[j], nee.uy[j], __uint_as_float(nee.light[j]), 0.0f);
+                }
             }
             outCount += (uint32_t)__popcll(mA); shCount += (uint32_t)__popcll(msA);
             outCountB = (uint32_t)__popcll(mB); shCountB = (uint32_t)__popcll(msB);
+            nEntriesOut += (unsigned int)(__popcll(msA) + __popcll(msB));
             if (SIMPLE) {
                 // ---- park the lanes that picked the specular lobe
                 const unsigned long long md = __ballot(wantDefer);
@@ -572,6 +606,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL > 1
             }
         }
     }
+    block_count_add_uniform<2>(a.counters, { 3, 5 }, { nEntriesOut, nRadiance });
 }
 
 // ------------------------------------------------------------------ shadow rays (scenes with non-opaque geometry)
@@ -642,12 +677,13 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
-    unsigned int nRays = 0;
+    unsigned int nRays = 0, nSamples = 0, nRadiance = 0;
     // one shadow-queue entry: every light sample of one path vertex
     auto process = [&](uint32_t e) {
                 float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], h4 = a.b.sh4[e];
                 f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), T = mk3(h4.x, h4.y, h4.z);
                 uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
+                nSamples += n;
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 for (uint32_t j = 0; j < n; ++j) {
                     uint32_t vis = kVisCandidates;
@@ -694,6 +730,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     float4 r = a.b.radiance[smp];
                     r.x = r.x + term.x; r.y = r.y + term.y; r.z = r.z + term.z;
                     a.b.radiance[smp] = r;
+                    ++nRadiance;
                 }
     };
     if (NONOPAQUE) {
@@ -729,6 +766,10 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
         }
     }
     block_count_add(&a.counters->closestRays, 1, nRays);
+    __syncthreads();
+    block_count_add(&a.counters->closestRays, 4, nSamples);
+    __syncthreads();
+    block_count_add(&a.counters->closestRays, 6, nRadiance);
 }
 
 // ------------------------------------------------------------------ resolve: fold the indices in order (:332-339)
@@ -807,7 +848,7 @@ void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
 bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& cb)
 {
     (void)scene;
-    return cb.m_LightCount <= kMaxLights && cb.m_MaxBounces >= 1;
+    return cb.m_MaxBounces >= 1;       // any number of lights: up to kMaxLights buffered per lane, beyond that streamed (wf_shade<0>)
 }
 
 void wavefront_release(WavefrontState& st)
@@ -837,7 +878,22 @@ void wavefront_collect_timing(WavefrontState& st)
 void wavefront_reset_timing(WavefrontState& st)
 {
     st.eventsUsed = 0;
-    for (int k = 0; k < 3; ++k) { st.kernelMs[k] = 0.0f; st.kernelLaunches[k] = 0; }
+    for (int k = 0; k < 5; ++k) { st.kernelMs[k] = 0.0f; st.kernelLaunches[k] = 0; }
+    st.raygenBytes = 0; st.resolveBytes = 0;
+}
+
+// Record sizes (the SoA streams of WfBuffers, 16 B per float4 stream):
+//   path record   rayO + rayD + thr (+ med0 + med1)              48 (80) B       hit record  16 B
+//   shadow entry  sh0 + sh1 + sh4 always read, sh2 + sh3 only for an entry with an unoccluded sample; + shL 16 B per light sample
+//   radiance      one float4 read-modify-write                    32 B
+// Any-hit schedule (kShadowResolve): per shadow ray sqO + sqD + sqId written and read (2 x 36 B), shVis written and read per light slot.
+void wavefront_queue_bytes(const WavefrontState& st, const DeviceCounters& c, uint64_t& trace, uint64_t& shade, uint64_t& shadow)
+{
+    const uint64_t path = st.layout.pathRecordBytes, survivors = c.closestRays > c.paths ? c.closestRays - c.paths : 0;
+    trace = c.closestRays * (32 + 16);
+    shade = c.closestRays * (path + 16) + survivors * path + c.neeEntries * 80 + c.neeSamples * 16 + c.radianceShade * 32;
+    shadow = c.neeEntries * 48 + c.neeSamples * 16 + c.radianceShadow * (32 + 32);
+    if (st.layout.shadowMode == kShadowResolve) shadow += c.neeEntries * 32 + c.neeSamples * 16 + c.shadowRays * 72 + c.neeEntries * st.layout.maxLights * 8;
 }
 
 namespace {
@@ -866,13 +922,25 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     hipError_t e;
     const uint32_t tilesX = rect.columns(), tilesY = (rect.y1 - rect.y0 + 7) / 8;
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64;
-    // batch the accumulation indices so that one batch stays below maxSamples
+    // batch the accumulation indices so that one batch stays below maxSamples AND its queue pool below a byte budget: the pool takes
+    // 240 B per sample with one light and no medium, but ~1.2 KB with 8 lights and non-opaque geometry (shadow-ray queue + candidate lists)
+    const uint32_t maxLights = constants.m_LightCount ? constants.m_LightCount : 1;
+    const uint64_t bytesPerSample = 16ull * (2 * (3 + (traits.hasMedium ? 2 : 0)) + 1 + 5 + maxLights + 1) +
+                                    ((traits.hasNonOpaque || maxLights > 1) ? (16ull + 16 + 4 + 4 + 8 * kShadowCandidates) * maxLights : 0);
     uint32_t sppPerBatch = accumCount < kMaxSppPerBatch ? accumCount : kMaxSppPerBatch;
-    const uint64_t maxSamples = st.maxSamplesPerBatch ? st.maxSamplesPerBatch : (64ull << 20);
+    uint64_t maxSamples = st.maxSamplesPerBatch ? st.maxSamplesPerBatch : (64ull << 20);
+    if (!st.maxSamplesPerBatch && pixelsPadded * sppPerBatch * bytesPerSample > st.poolBytes) {
+        // the pool has to grow: keep it within half of what the device has free (other contexts -- a second frame in flight -- need theirs)
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const uint64_t budget = (uint64_t)(freeB + st.poolBytes) / 2;
+            if (budget / bytesPerSample < maxSamples) maxSamples = budget / bytesPerSample;
+        }
+    }
+    if (maxSamples * maxLights > 0xFFFFFFFFull) maxSamples = 0xFFFFFFFFull / maxLights;      // (entry, light) slot ids are 32-bit
     while (sppPerBatch > 1 && pixelsPadded * sppPerBatch > maxSamples) --sppPerBatch;
     const uint64_t capacity = ((pixelsPadded * sppPerBatch + kMaxSegment - 1) / kMaxSegment) * kMaxSegment;
     if (capacity >= (1ull << 31)) { error = "tile too large for one batch"; return hipErrorInvalidValue; }
-    const uint32_t maxLights = constants.m_LightCount ? constants.m_LightCount : 1;
     const uint32_t segs = (uint32_t)(capacity / 64);   // counter arrays sized for the smallest segment
 
     // ---- pool layout
@@ -896,7 +964,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     if (off > st.poolBytes) {
         if (st.pool) { (void)hipStreamSynchronize(stream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
         e = hipMalloc(&st.pool, off);
-        if (e != hipSuccess) { error = "hipMalloc(queue pool)"; return e; }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            error = "hipMalloc(queue pool, " + std::to_string(off >> 20) + " MiB for " + std::to_string(capacity) + " samples; render a smaller tile)";
+            return e;
+        }
         st.poolBytes = off;
     }
     char* base = static_cast<char*>(st.pool);
@@ -913,6 +985,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.b.sqO = (float4*)(base + oSqO); a.b.sqD = (float4*)(base + oSqD); a.b.sqId = (uint32_t*)(base + oSqId); a.b.sqCnt = (uint32_t*)(base + oSqCnt); a.b.shVis = (uint32_t*)(base + oShVis); a.b.sqCand = (uint2*)(base + oSqCand);
     a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
     a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
+    st.layout.pathRecordBytes = traits.hasMedium ? 80u : 48u; st.layout.maxLights = maxLights;
     a.counters = counters;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
     a.streamSegments = st.drainSegments ? 0u : 1u;
@@ -952,8 +1025,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     int shadowMode = (!vS.lds && unevenRays) ? kShadowResolve : selfMode;
     if (st.shadowPath == 1) shadowMode = selfMode;
     if (st.shadowPath == 2 && (traits.hasNonOpaque || maxLights > 1)) shadowMode = kShadowResolve;
-    const Variant vA = pick(forced ? forced : 4, candBytes, kExtendLdsStack);     // any-hit pass over the shadow rays (same kernel family as vE)
+    // any-hit pass over the shadow rays (same kernel family as vE). wf_extend<ANYHIT> always carves its candidate columns out of LDS
+    // (launch_extend_t adds them to the launch), opaque scene or not, so the budget check must count them too.
+    const Variant vA = pick(forced ? forced : 4, (size_t)kShadowCandidates * 2 * kBlock * 4, kExtendLdsStack);
     if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
+    st.layout.shadowMode = shadowMode;
     // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py). A context that is one lane of a
     // two-frames-in-flight loop (hrpt_set_shadow_overlap(ctx, 0)) and traverses a tree in global memory does better with half the grid:
     // its latency-bound kernels leave room for the other lane's (config 4 14.4 -> 14.0 ms, config 5 22.6 -> 21.9 ms per frame).
@@ -999,7 +1075,16 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             jt.j[k].x = hrpt_halton(cb.m_AccumulationIndex + k + 1, 2) - 0.5f;
             jt.j[k].y = hrpt_halton(cb.m_AccumulationIndex + k + 1, 3) - 0.5f;
         }
+        const bool timedEnds = st.profile && st.eventsUsed + 4 <= 4096;
+        if (timedEnds) timing_mark(st, stream, 3, true);
         hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
+        if (timedEnds) timing_mark(st, stream, 3, false);
+        {   // raygen: sampleRadiance zeroed + one path record per pixel of the rectangle and index; resolve: sampleRadiance read, Accumulation
+            // read (when resuming) and written, Output written
+            const uint64_t w = (uint64_t)rect.columns() * 8u, px = (w < rect.x1 - rect.x0 ? w : (uint64_t)rect.x1 - rect.x0) * (rect.y1 - rect.y0);
+            st.raygenBytes += (uint64_t)a.numSamples * 16 + px * spp * st.layout.pathRecordBytes;
+            st.resolveBytes += px * ((uint64_t)spp * 16 + 32 + (cb.m_AccumulationIndex > 0 ? 16 : 0));
+        }
         const int maxBounces = (int)cb.m_MaxBounces;
         // wf_shadow(b) only reads the shadow queue of shade(b) and adds into sampleRadiance; wf_extend(b+1) reads the path queue and
         // writes hit records: no shared buffer, so the two run concurrently (fork after shade(b), join before shade(b+1), which both
@@ -1028,13 +1113,14 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         bool pendingJoin = false;
         for (int bounce = 0; bounce < maxBounces; ++bounce) {
             const uint32_t parity = (uint32_t)bounce & 1u;
-            const bool timed = st.profile && st.eventsUsed + 6 <= 4096;
+            const bool timed = st.profile && st.eventsUsed + 8 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
             launch_extend(vE, dim3(grid), vE.ldsBytes, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
-            if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
@@ -1050,7 +1136,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         }
         if (pendingJoin && (e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)maxBounces - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; }
         uint32_t rgrid = (uint32_t)((pixelsPadded + kBlock - 1) / kBlock); if (rgrid > cus * 8) rgrid = cus * 8;
+        if (timedEnds) timing_mark(st, stream, 4, true);
         hipLaunchKernelGGL(wf_resolve, dim3(rgrid), dim3(kBlock), 0, stream, a, accumulation, output, cb.m_AccumulationIndex);
+        if (timedEnds) timing_mark(st, stream, 4, false);
         if ((e = hipGetLastError()) != hipSuccess) { error = "kernel launch"; return e; }
     }
     return hipSuccess;

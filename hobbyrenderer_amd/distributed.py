@@ -127,6 +127,9 @@ class PipelinedFrames:
             self.comm = torch.cuda.Stream(device)
             self.rendered = [torch.cuda.Event() for _ in range(2)]
             self.delivered = [torch.cuda.Event() for _ in range(2)]
+            # device time of the comm-stream work (all-gather + re-assembly + resolve) of the frame in each slot
+            self.gather_begin = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self.gather_end = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def submit(self):
         """Enqueue one frame; returns the slot (0/1) whose `gathered`/`output` images will hold it."""
@@ -143,7 +146,9 @@ class PipelinedFrames:
                 self.rendered[s].record(main)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.rendered[s])
+                self.gather_begin[s].record(self.comm)
                 self._gather_and_resolve(s, self.comm.cuda_stream)
+                self.gather_end[s].record(self.comm)
                 self.delivered[s].record(self.comm)
         else:
             self.render_band[lane](self.y0, self.y1)
@@ -162,6 +167,13 @@ class PipelinedFrames:
                 return
             columns_to_image(self.shards[s], self.world, self.gathered[s])     # one 16 B/pixel pass on the comm stream
         self.resolve(self.gathered[s], self.output[s], stream_handle)
+
+    def gather_ms(self):
+        """Device time of the last submitted frame's comm-stream work (all-gather + resolve); call after the streams were synchronised."""
+        if not self.gpu or self.frame == 0:
+            return 0.0
+        s = (self.frame - 1) & 1
+        return float(self.gather_begin[s].elapsed_time(self.gather_end[s]))
 
     def finish(self):
         """Make the current stream wait for every submitted frame (host synchronisation stays with the caller)."""

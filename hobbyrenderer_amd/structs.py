@@ -91,7 +91,12 @@ class Stats(C.Structure):
                 ("lastRenderMs", C.c_float), ("traceKernelMs", C.c_float), ("traceKernelLaunches", C.c_uint32),
                 ("shadeKernelMs", C.c_float), ("shadeKernelLaunches", C.c_uint32),
                 ("shadowKernelMs", C.c_float), ("shadowKernelLaunches", C.c_uint32),
-                ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("bvhMaxDepth", C.c_uint32)]
+                ("bvhNodeCount", C.c_uint32), ("bvhTriangleCount", C.c_uint32), ("bvhMaxDepth", C.c_uint32),
+                ("megakernelFallbacks", C.c_uint32), ("raygenKernelMs", C.c_float), ("raygenKernelLaunches", C.c_uint32),
+                ("resolveKernelMs", C.c_float), ("resolveKernelLaunches", C.c_uint32), ("pad0", C.c_uint32),
+                ("raygenQueueBytes", C.c_uint64), ("traceQueueBytes", C.c_uint64), ("shadeQueueBytes", C.c_uint64),
+                ("shadowQueueBytes", C.c_uint64), ("resolveQueueBytes", C.c_uint64), ("neeEntries", C.c_uint64),
+                ("neeSamples", C.c_uint64), ("queuePoolBytes", C.c_uint64)]
 
 
 Ray = np.dtype([("origin", f32, 3), ("tmin", f32), ("direction", f32, 3), ("tmax", f32), ("rng", u32), ("pad", u32, 3)])       # HrptRay, 48 B
@@ -105,7 +110,7 @@ class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
                 ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("pad", C.c_uint32 * 1)]
 
 
-ABI_VERSION = 2                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)
+ABI_VERSION = 3                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)
 BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC, BVH_BUILDER_AUTO = 0, 1, 2, 3
 
 

@@ -28,7 +28,8 @@
 #define HRT_FN static inline
 #endif
 
-#define HRT_PI 3.14159265359f /* srrhi::CommonConsts::PI, shaders/Common.sr:50 */
+#define HRT_PI 3.14159265359f /* srrhi::CommonConsts::PI, shaders/Common.sr:48 */
+#define HRT_K_EPSILON 1e-5f /* srrhi::CommonConsts::kEpsilon, shaders/Common.sr:50 ("general-purpose epsilon for division/sqrt guards"); PathTracer.hlsl:218 */
 
 HRT_FN float hrt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 HRT_FN uint32_t hrt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HRPT_ABI_VERSION 2
+#define HRPT_ABI_VERSION 3
 
 typedef enum HrptStatus {
     HRPT_OK = 0,
@@ -239,6 +239,25 @@ typedef struct HrptStats {
     uint32_t bvhNodeCount;
     uint32_t bvhTriangleCount;
     uint32_t bvhMaxDepth;
+    /* ---- ABI 3: queue accounting of the wavefront pipeline (cumulative since hrpt_reset_stats) -------------------------------
+     * Bytes each kernel class moves through its queue streams in HBM: records read / written x record size, from counters the
+     * kernels keep (paths per bounce, shadow-queue entries, light samples, sampleRadiance updates) and the record layouts of the
+     * configuration the LAST hrpt_render used. BVH nodes / triangles / attribute records / textures are not included: they are served
+     * by LDS and L2 (rocprofv3 FETCH_SIZE / WRITE_SIZE give the HBM total). Zero in megakernel mode. */
+    uint32_t megakernelFallbacks;          /* hrpt_render calls that asked for the wavefront pipeline but ran the validation megakernel */
+    float    raygenKernelMs;               /* wf_raygen (HRPT_FRAME_PROFILE) */
+    uint32_t raygenKernelLaunches;
+    float    resolveKernelMs;              /* wf_resolve (HRPT_FRAME_PROFILE) */
+    uint32_t resolveKernelLaunches;
+    uint32_t pad0;
+    uint64_t raygenQueueBytes;
+    uint64_t traceQueueBytes;              /* ray records read + hit records written */
+    uint64_t shadeQueueBytes;              /* path + hit records read, surviving paths + shadow-queue entries written, sampleRadiance updates */
+    uint64_t shadowQueueBytes;             /* shadow-queue entries + light samples read, sampleRadiance updates (+ shadow-ray queue in the any-hit schedule) */
+    uint64_t resolveQueueBytes;            /* sampleRadiance read, Accumulation read / written, Output written */
+    uint64_t neeEntries;                   /* path vertices with at least one light sample */
+    uint64_t neeSamples;                   /* light samples drawn (>= shadowRays: a sample below the horizon traces no ray) */
+    uint64_t queuePoolBytes;               /* size of the context's queue pool in HBM */
 } HrptStats;
 
 typedef struct HrptContext HrptContext;

@@ -1200,7 +1200,7 @@ static void trace_pixel(Tls* tl, const HrptPathTracerConstants* cb, uint32_t px,
                         refractedDir = normalize3(refractedDir);
                         float alpha = pbr.roughness * pbr.roughness, alpha2 = alpha * alpha;
                         float NdotL_t = hrt_abs(dot3(N, refractedDir));
-                        float G1_t = (NdotL_t > 1e-5f) ? 2.0f * NdotL_t / (NdotL_t + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL_t * NdotL_t)) : 0.0f;
+                        float G1_t = (NdotL_t > HRT_K_EPSILON) ? 2.0f * NdotL_t / (NdotL_t + hrt_sqrt(alpha2 + (1.0f - alpha2) * NdotL_t * NdotL_t)) : 0.0f;
                         bsdfWeight = scale3(scale3(scale3(pbr.baseColor, 1.0f - F_mf), G1_t), NdotL_t);
                     }
                     throughput = mul3(throughput, bsdfWeight);

@@ -20,10 +20,25 @@ def test_every_declared_symbol_is_exported():
         assert getattr(native.lib, name) is not None
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(S.SceneDesc) == 136 and C.sizeof(S.TextureDesc) == 16 and C.sizeof(S.DeviceDesc) == 8
+def test_struct_sizes_match_header(tmp_path):
+    """The ctypes / numpy mirrors against the C header itself: a C program compiled from include/hobbyrt_pt.h prints sizeof and the
+    offset of every HrptStats field."""
+    import subprocess
+    fields = [f for f, _ in S.Stats._fields_]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hobbyrt_pt.h"\nint main(void){\n'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(HrptSceneDesc), sizeof(HrptTextureDesc), sizeof(HrptDeviceDesc), sizeof(HrptFrameParams), '
+                   'sizeof(HrptStats), sizeof(HrptBuildInfo), sizeof(HrptRay), sizeof(HrptRayHit));\n' +
+                   "".join(f'printf("%zu\\n", offsetof(HrptStats, {f}));\n' for f in fields) + "printf(\"%d\\n\", HRPT_ABI_VERSION);return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    sizes = [int(x) for x in out[:8]]
+    assert sizes == [C.sizeof(S.SceneDesc), C.sizeof(S.TextureDesc), C.sizeof(S.DeviceDesc), S.FrameParams.itemsize, C.sizeof(S.Stats),
+                     C.sizeof(S.BuildInfo), S.Ray.itemsize, S.RayHit.itemsize], sizes
+    assert [int(x) for x in out[8:8 + len(fields)]] == [getattr(S.Stats, f).offset for f in fields]
+    assert int(out[-1]) == S.ABI_VERSION
     assert S.FrameParams.itemsize == 768 + 8 * 4
-    assert C.sizeof(S.Stats) == 64
 
 
 def test_no_device_fails_loudly(gpu_available):

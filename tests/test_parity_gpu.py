@@ -73,6 +73,36 @@ def test_cornell_point_and_spot_lights(ctx, luts, flags):
     _assert_parity(*_run_both(ctx, sc, view, pos, 160, 90, 4, 6, flags))
 
 
+def _many_lights(sc, n):
+    """n lights in the reference's buffer order (spot, point, directional last is NOT required here: the default sun stays first as
+    config_cornell built it; g_Lights[0] is what the sun-intensity quirk reads)."""
+    rng = np.random.default_rng(77)
+    extra = np.zeros(n - len(sc.lights), S.GPULight)
+    for i in range(len(extra)):
+        spot = i % 3 == 0
+        extra[i]["m_Type"] = S.LIGHT_SPOT if spot else S.LIGHT_POINT
+        extra[i]["m_Position"] = (rng.uniform(-0.8, 0.8), rng.uniform(0.5, 1.8), rng.uniform(-0.8, 0.8))
+        d = np.array([rng.uniform(-0.4, 0.4), -1.0, rng.uniform(-0.4, 0.4)]); d /= np.linalg.norm(d)
+        extra[i]["m_Direction"] = d
+        extra[i]["m_Color"] = tuple(rng.uniform(0.3, 1.0, 3)); extra[i]["m_Intensity"] = rng.uniform(2.0, 8.0)
+        extra[i]["m_Range"] = 0.0 if i % 4 == 1 else 12.0; extra[i]["m_Radius"] = 0.03
+        extra[i]["m_SpotInnerConeAngle"] = 0.4; extra[i]["m_SpotOuterConeAngle"] = 0.9
+    sc.lights = np.concatenate([np.asarray(sc.lights, S.GPULight), extra])
+    return sc
+
+
+@pytest.mark.parametrize("n_lights", [9, 12, 20])
+def test_more_than_eight_lights_stay_on_the_wavefront_path(ctx, luts, n_lights):
+    """AccumulateDirectLighting loops over all m_LightCount lights (CommonLighting.hlsli:877-908). Up to 8 light samples are buffered per
+    lane; beyond that wf_shade<0> replays the light loop's draws into the entry's slots. No silent megakernel fallback."""
+    sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54, extra_lights=True)
+    sc = _many_lights(sc, n_lights)
+    acc, out, st, oacc, oout, ost = _run_both(ctx, sc, view, pos, 96, 54, 2, 5, S.FRAME_DEFAULT)
+    _assert_parity(acc, out, st, oacc, oout, ost)
+    assert st.megakernelFallbacks == 0 and st.shadeKernelLaunches == 0 and st.neeEntries > 0 and st.shadeQueueBytes > 0
+    assert st.neeSamples >= st.shadowRays > 0
+
+
 # ---- every material class of the path: MASK, stochastic BLEND, thick / thin transmission, textures ----------
 from scene_helpers import random_soup
 
@@ -263,6 +293,21 @@ def test_forced_shadow_path(luts, path, monkeypatch):
         _assert_parity(*_run_both(c, sc, view, pos, 64, 48, 2, 6, S.FRAME_WAVEFRONT))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n_tris", [330, 390, 450, 510, 570])
+def test_opaque_multilight_scene_in_the_lds_window_of_the_anyhit_pass(ctx, luts, n_tris):
+    """An all-opaque scene with several lights whose 4-wide tree fits LDS next to the 16-entry closest-hit stacks but not next to the
+    32-entry shadow stacks takes the any-hit schedule (wf_shadow_rays + wf_extend<ANYHIT> + resolve). wf_extend<ANYHIT> always carves
+    16 KB of candidate columns out of LDS, so its variant must budget for them (round 1 did not: the launch asked for up to 80 KB)."""
+    sc = random_soup(luts, n_tris, 500 + n_tris)
+    lights = list(sc.lights)
+    extra = np.zeros(2, S.GPULight)
+    extra["m_Type"] = S.LIGHT_POINT; extra["m_Position"] = [(-0.8, 2.0, 0.5), (1.0, 1.5, -1.5)]; extra["m_Intensity"] = 15.0
+    extra["m_Color"] = (1.0, 1.0, 1.0); extra["m_Radius"] = 0.05
+    sc.lights = np.concatenate([np.asarray(lights, S.GPULight), extra])
+    view, pos = scenes.planar_view(64, 48, position=(0.2, 0.3, -5.0), aspect=64 / 48)
+    _assert_parity(*_run_both(ctx, sc, view, pos, 64, 48, 2, 4, S.FRAME_WAVEFRONT))
 
 
 # ---- GPU-built acceleration structure (SURVEY.md 8f #4): same radiance bits as with the host SAH build ----------
