@@ -259,7 +259,7 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     for (uint32_t i = 0; i < s.instanceCount; ++i) {
         const HrptPerInstanceData& in = s.instances[i];
         const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
-        uint32_t opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+        uint32_t opaque = triangle_flags_for_material(s.materials[in.m_MaterialIndex]);     // bit 0 opaque, bits 1-2 shading class
         for (uint32_t p = 0; p < md.m_IndexCounts[0] / 3; ++p) {
             const uint32_t* ix = s.indices + md.m_IndexOffsets[0] + 3 * (size_t)p;
             HostTri t;

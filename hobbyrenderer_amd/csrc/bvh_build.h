@@ -18,6 +18,18 @@
 
 namespace hrt {
 
+// GpuTri::flags of every triangle of an instance with material m: bit 0 = the instance is ForceOpaque (alpha mode OPAQUE,
+// src/Scene.cpp:150-154); bits 1-2 = shading class, which wf_extend copies into the hit record so that wf_shade can group the paths of
+// a segment by the code path they will take (north_star: "ray compaction/sort by material"):
+//   0 constants only   1 samples textures (RaytracingCommon.hlsli:252-296)   2 takes the transmission branch (PathTracer.hlsl:149-255)
+inline uint32_t triangle_flags_for_material(const HrptMaterialConstants& m)
+{
+    const uint32_t opaque = m.m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+    const bool transmissive = m.m_TransmissionFactor > 0.0f || m.m_AlphaMode == HRPT_ALPHA_MODE_BLEND;
+    const uint32_t cls = transmissive ? 2u : (m.m_TextureFlags != 0 ? 1u : 0u);
+    return opaque | (cls << 1);
+}
+
 struct HostNode {           // mirrors hrt::GpuNode (pt_device.h), 64 B
     float lmin[3]; int32_t left;
     float lmax[3]; int32_t right;
@@ -30,9 +42,11 @@ struct HostTri {            // mirrors hrt::GpuTri, 48 B
     float p2[3]; uint32_t flags;
 };
 // 4-wide node for the wavefront kernels (collapsed from the BVH2): child boxes in SoA (x of 4 children, y, z, ...) so
-// the four slab tests are data-parallel; 128 B = two cache lines fetched together. Empty slots: min = +inf, max = -inf.
+// the four slab tests are data-parallel; 128 B = two cache lines fetched together. Empty slots: a degenerate box at 1e30.
+// Row order min/max interleaved per axis: the traversal picks the NEAR row of an axis by the sign of the ray direction
+// (byte offset axis * 32 + (d < 0 ? 16 : 0)) and gets the far row as near ^ 16 (pt_device.h inner_step).
 struct HostNode4 {
-    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
     int32_t child[4];               // >= 0 inner node4 index, < 0 leaf (same encoding as HostNode), kEmptyChild = unused slot
     uint32_t pad[4];
 };

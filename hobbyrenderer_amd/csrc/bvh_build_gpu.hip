@@ -10,6 +10,7 @@
 // candidates revisited through exclusive lower keys), boxes are padded conservatively with the host builder's rule, and the world
 // transform / attribute unpacking use the same expression order with -ffp-contract=off.
 #include "bvh_build_gpu.h"
+#include "bvh_build.h"
 
 #include <cstring>
 using std::memset;   // rocprim/iterator/texture_cache_iterator.hpp calls an unqualified memset
@@ -574,7 +575,7 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
         const HrptPerInstanceData& in = s.instances[i];
         const HrptMeshData& md = s.meshData[in.m_MeshDataIndex];
         m.inst[i].indexOffset = md.m_IndexOffsets[0]; m.inst[i].triBase = (uint32_t)T; m.inst[i].material = in.m_MaterialIndex;
-        m.inst[i].opaque = s.materials[in.m_MaterialIndex].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE ? 1u : 0u;
+        m.inst[i].opaque = triangle_flags_for_material(s.materials[in.m_MaterialIndex]);     // bit 0 opaque, bits 1-2 shading class
         T += md.m_IndexCounts[0] / 3;
     }
     if (T < 8 || T >= (1ull << 29)) { error = "triangle count outside the GPU builder's range"; return hipErrorInvalidValue; }

@@ -148,6 +148,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_DRAIN_SEGMENTS")) c->wf.drainSegments = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SHADOW_PATH")) c->wf.shadowPath = atoi(e);
+    if (const char* e = getenv("HRPT_WF_SHADE_SORT")) c->wf.noShadeSort = atoi(e) == 0;
     *out = c;
     return HRPT_OK;
 }
@@ -393,7 +394,7 @@ static int update_materials_impl(HrptContext* c, const HrptMaterialConstants* ma
     const bool tangentsBefore = scene_needs_tangents(before);
     bool structural = false;
     for (uint32_t i = 0; i < count; ++i)
-        if ((materials[i].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE) != (c->keptMaterials[firstMaterial + i].m_AlphaMode == HRPT_ALPHA_MODE_OPAQUE)) structural = true;
+        if (triangle_flags_for_material(materials[i]) != triangle_flags_for_material(c->keptMaterials[firstMaterial + i])) structural = true;   // opacity or shading class
     std::memcpy(c->keptMaterials.data() + firstMaterial, materials, (size_t)count * sizeof(HrptMaterialConstants));
     HIP_TRY(c, hipMemcpyAsync(const_cast<HrptMaterialConstants*>(c->view.materials) + firstMaterial, materials, (size_t)count * sizeof(HrptMaterialConstants), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -64,7 +64,7 @@ struct GpuNode {            // 64 B: both child boxes live in the parent -> one 
     float rmax[3]; uint32_t pad1;
 };
 struct GpuNode4 {           // 128 B: four child boxes in SoA + four child refs (bvh_build.h HostNode4); empty slot = far-away box
-    float4 minx, miny, minz, maxx, maxy, maxz; int4 child; uint4 pad;
+    float4 minx, maxx, miny, maxy, minz, maxz; int4 child; uint4 pad;     // rows at byte 0, 16, ..., 80; child refs at 96
 };
 struct GpuTri {             // 48 B world-space triangle (instance transform applied at upload)
     float p0[3]; uint32_t inst;
@@ -162,17 +162,15 @@ struct GlobalBvh {
 struct GlobalBvh4 {
     static constexpr int kWidth = 4;
     const GpuNode4* nodes; const GpuTri* tris;
-    HRT_DEV void node4(int i, float4& mnx, float4& mny, float4& mnz, float4& mxx, float4& mxy, float4& mxz, int4& ch) const
-    {
-        const float4* p = reinterpret_cast<const float4*>(nodes + i);
-        mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5];
-        float4 c = p[6]; ch = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
-    }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
     {
         const float4* p = reinterpret_cast<const float4*>(tris + i);
         a = p[0]; b = p[1]; c = p[2];
     }
+    // one 16-byte row of node i: byte offset 0/16 = min/max x of the four children, 32/48 = y, 64/80 = z, 96 = child refs
+    HRT_DEV const char* rowptr(int i, uint32_t byteOffset) const { return reinterpret_cast<const char*>(nodes) + ((size_t)(uint32_t)i * 128u + byteOffset); }
+    HRT_DEV float4 row(int i, uint32_t byteOffset) const { return *reinterpret_cast<const float4*>(rowptr(i, byteOffset)); }
+    static HRT_DEV const char* flip16(const char* p) { return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(p) ^ (uintptr_t)16); }
 };
 
 // Conservative slab test of one child box against [t0, t1]. Culling only: it never changes which hit is
@@ -231,13 +229,30 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tm
         if (hr) return ri;
         return (sp == 0) ? kTraversalDone : stack.pop(--sp);
     } else {
-        float4 mnx, mny, mnz, mxx, mxy, mxz; int4 ch;
-        bvh.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, ch);
-        float t0 = slab1(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, noi, inv, tmin, tlim);
-        float t1 = slab1(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, noi, inv, tmin, tlim);
-        float t2 = slab1(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, noi, inv, tmin, tlim);
-        float t3 = slab1(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, noi, inv, tmin, tlim);
-        int32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
+        // The sign of the ray direction says which plane of every slab is the near one, so the near / far rows of the node are picked by
+        // ADDRESS (min / max rows of an axis are 16 bytes apart: far = near ^ 16) instead of by six min/max per child box, and the 2e-6
+        // relative widening of both ends is folded into one 4e-6 scale of the far end (hi > 0 whenever the test can pass: lo >= tmin >= 0).
+        const uint32_t nx = inv.x < 0.0f ? 16u : 0u, ny = inv.y < 0.0f ? 48u : 32u, nz = inv.z < 0.0f ? 80u : 64u;
+        // (the far address is derived from the NEAR ADDRESS, not from the offset: offsets are loop-invariant per ray and the compiler
+        // would otherwise keep all six in registers -- +6 VGPRs cost the kernel a wave of occupancy; nodes are 128-byte aligned)
+        const char* const pnx = bvh.rowptr(cur, nx); const char* const pny = bvh.rowptr(cur, ny); const char* const pnz = bvh.rowptr(cur, nz);
+        const float4 anx = *reinterpret_cast<const float4*>(pnx), any = *reinterpret_cast<const float4*>(pny), anz = *reinterpret_cast<const float4*>(pnz);
+        const float4 afx = *reinterpret_cast<const float4*>(BVH::flip16(pnx)), afy = *reinterpret_cast<const float4*>(BVH::flip16(pny)),
+                     afz = *reinterpret_cast<const float4*>(BVH::flip16(pnz));
+        const float4 chf = bvh.row(cur, 96u);
+        auto box = [&](float bnx, float bny, float bnz, float bfx, float bfy, float bfz) {
+            const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(bnx, inv.x, noi.x), __builtin_fmaf(bny, inv.y, noi.y)), __builtin_fmaf(bnz, inv.z, noi.z)), tmin);
+            const float far3 = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bfx, inv.x, noi.x), __builtin_fmaf(bfy, inv.y, noi.y)), __builtin_fmaf(bfz, inv.z, noi.z));
+            // the scale comes AFTER the clamp to tlim: a second triangle at exactly the distance of the best hit so far (shared edges,
+            // coplanar duplicates: the tie is decided by (instance, primitive)) must survive a near distance that rounds just above tlim
+            const float hi = __builtin_fminf(far3, tlim) * (1.0f + 4e-6f);
+            return lo <= hi ? lo : __builtin_inff();
+        };
+        float t0 = box(anx.x, any.x, anz.x, afx.x, afy.x, afz.x);
+        float t1 = box(anx.y, any.y, anz.y, afx.y, afy.y, afz.y);
+        float t2 = box(anx.z, any.z, anz.z, afx.z, afy.z, afz.z);
+        float t3 = box(anx.w, any.w, anz.w, afx.w, afy.w, afz.w);
+        int32_t r0 = __float_as_int(chf.x), r1 = __float_as_int(chf.y), r2 = __float_as_int(chf.z), r3 = __float_as_int(chf.w);
         cswap(t0, r0, t1, r1); cswap(t2, r2, t3, r3); cswap(t0, r0, t2, r2); cswap(t1, r1, t3, r3); cswap(t1, r1, t2, r2);
         const float inf = __builtin_inff();
         if (t3 < inf) stack.push(sp++, r3);

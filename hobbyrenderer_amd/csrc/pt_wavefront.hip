@@ -66,6 +66,7 @@ struct WfArgs {
     uint32_t hasStochasticAlpha;
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
+    uint32_t sortShade;        // wf_shade (general variants) shades the entries of a segment grouped by shading class
     int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
     DeviceCounters* counters;
 };
@@ -94,6 +95,7 @@ template <int DEPTH, int LDSMAX>
 struct LdsStack {
     static constexpr int kLdsStackMax = LDSMAX;
     static constexpr int kLds = DEPTH > kLdsStackMax ? kLdsStackMax : DEPTH;
+    static constexpr int kRows = kLds;
     int32_t* base; int32_t* spill; uint32_t spillStride;
     HRT_DEV void push(int sp, int32_t v)
     {
@@ -126,13 +128,16 @@ struct LdsBvh {
     static constexpr int kWidth = W;
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
-    HRT_DEV void node4(int i, float4& mnx, float4& mny, float4& mnz, float4& mxx, float4& mxy, float4& mxz, int4& ch) const
-    {
-        const float4* p = nodes + 8 * i;
-        mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5];
-        float4 c = p[6]; ch = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
-    }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
+    HRT_DEV const char* rowptr(int i, uint32_t byteOffset) const { return reinterpret_cast<const char*>(nodes + 8 * i) + byteOffset; }
+    HRT_DEV float4 row(int i, uint32_t byteOffset) const { return *reinterpret_cast<const float4*>(rowptr(i, byteOffset)); }
+    // LDS addresses are 32-bit: flip bit 4 of the LDS offset (the copy starts 128-byte aligned: setup_lds)
+    static HRT_DEV const char* flip16(const char* p)
+    {
+        typedef __attribute__((address_space(3))) const char* LdsPtr;
+        const uint32_t o = (uint32_t)(uintptr_t)(LdsPtr)p ^ 16u;
+        return (const char*)(LdsPtr)(uintptr_t)o;
+    }
 };
 template <int W> struct GlobalBvhOf;
 template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV GlobalBvh make(const SceneView& s) { GlobalBvh g; g.nodes = s.nodes; g.tris = s.tris; return g; } };
@@ -145,7 +150,7 @@ HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH, LDSMAX>& 
     stack.base = reinterpret_cast<int32_t*>(smem) + threadIdx.x;
     stack.spill = nullptr; stack.spillStride = 0;
     if (LDS_BVH) {
-        float4* dst = reinterpret_cast<float4*>(smem + (size_t)LdsStack<DEPTH, LDSMAX>::kLds * kBlock * 4 + extraBytes);
+        float4* dst = reinterpret_cast<float4*>(smem + (size_t)LdsStack<DEPTH, LDSMAX>::kRows * kBlock * 4 + extraBytes);
         const float4* srcN = W == 2 ? reinterpret_cast<const float4*>(s.nodes) : reinterpret_cast<const float4*>(s.nodes4);
         const float4* srcT = reinterpret_cast<const float4*>(s.tris);
         uint32_t nN = W == 2 ? s.nodeCount * 4 : s.node4Count * 8, nT = s.triCount * 3;
@@ -157,6 +162,10 @@ HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH, LDSMAX>& 
 }
 
 HRT_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+// A value every lane of the wave holds identically (segment cursors, counts read from memory, the wave's index), moved to a scalar
+// register: the compiler cannot prove uniformity of anything derived from threadIdx or from a load, and would otherwise keep such cursors
+// in VGPRs and turn every test on them into an exec-mask branch.
+HRT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 HRT_DEV uint32_t prefix_rank(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
 
 HRT_DEV unsigned long long wave_sum_u32(unsigned int v)
@@ -199,7 +208,7 @@ HRT_DEV void block_count_add_uniform(DeviceCounters* counters, const int (&field
 __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerConstants cb, JitterTable jt)
 {
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
-    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nPaths = 0;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
         uint32_t segBase = seg << a.segShift, outCount = 0;
@@ -262,19 +271,19 @@ constexpr uint32_t kRefillMinDefault = 12;
 // triangle ends the ray (kVisBlocked); otherwise the ray is clear or, if it crossed non-opaque triangles, left to wf_shadow's candidate
 // pass (kVisCandidates). Shadow rays get the lane refill closest-hit rays have: 3.8 -> 8 Grays/s on the glass config.
 template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT>
-__global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void wf_extend(WfArgs a, uint32_t parity)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = ANYHIT ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
-    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kLds * kBlock * 4) + threadIdx.x;
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kRows * kBlock * 4) + threadIdx.x;
     if (DEPTH > kExtendLdsStack) { stack.spill = a.spill[ANYHIT ? 1 : 0] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
 
-    const uint32_t wavesPerBlock = kBlock / 64;
-    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     const float4* __restrict__ rayO = ANYHIT ? a.b.sqO : a.b.rayO[parity];
     float4* __restrict__ rayD = ANYHIT ? a.b.sqD : a.b.rayD[parity];
     const uint32_t* __restrict__ segCount = ANYHIT ? a.b.sqCnt : a.b.pathCnt[parity];
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
         auto open_segment = [&]() {                             // first non-empty segment at or after `seg`
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = segCount[seg];
+                cnt = uniform(segCount[seg]);
                 if (cnt) { segBase = (seg << a.segShift) * slotsPerSample; haveSeg = true; break; }
             }
         };
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
             unsigned long long mIdle = __ballot(!active);
             uint32_t nIdle = (uint32_t)__popcll(mIdle);
             if (haveSeg && (nIdle >= a.refillMin || nIdle == 64u)) {
-                uint32_t idx = next + prefix_rank(mIdle);
+                const uint32_t idx = next + prefix_rank(mIdle);
                 if (!active && idx < cnt) {
                     slot = segBase + idx;
                     float4 o = rayO[slot], d = rayD[slot];
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                             bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
                             if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
                                 best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
-                                best.opaque = __float_as_uint(tc.w) & 1u; best.tri = first + i;
+                                best.opaque = __float_as_uint(tc.w) & 7u; best.tri = first + i;     // bit 0 opaque, bits 1-2 shading class
                                 tlim = t;
                             }
                         }
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                     }
                 } else if (cur == kTraversalDone) {
                     bool done = true;
-                    if (best.valid && !best.opaque && !candidate_commits(s, best, rng)) {
+                    if (best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
                         // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
                         lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
                         best.valid = false; tlim = r.tmax; sp = 0;
@@ -382,7 +391,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(WfArgs a, uint32_t parity)
                     }
                     if (done) {
                         if (a.hasStochasticAlpha && rng != rng0) { float4 d = rayD[slot]; d.w = __uint_as_float(rng); rayD[slot] = d; }
-                        a.b.hit[slot] = make_float4(best.t, best.u, best.v, __uint_as_float(best.valid ? best.tri : 0xFFFFFFFFu));
+                        // hit record: triangle (< 2^29: leaf references hold first << 2) | shading class << 29; 0xFFFFFFFF = miss
+                        a.b.hit[slot] = make_float4(best.t, best.u, best.v, __uint_as_float(best.valid ? (best.tri | ((best.opaque >> 1) << 29)) : 0xFFFFFFFFu));
                         active = false;
                     }
                 }
@@ -408,7 +418,7 @@ template <int MAXL, bool SIMPLE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 1 ? 4 : 3, MAXL != 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
-    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     const uint32_t in = parity, out = parity ^ 1u;
     const SceneView& s = a.scene;
     // Deferred specular lobe (SIMPLE variant). On diffuse-dominated scenes ~10 % of the paths pick the GGX-VNDF lobe, a long branch that
@@ -417,9 +427,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
     // belong to that segment). Per path the arithmetic is unchanged.
     extern __shared__ __attribute__((aligned(16))) char shadeSmem[];
     constexpr uint32_t kRing = 128, kRingFields = 23;
-    float* const ring = reinterpret_cast<float*>(shadeSmem) + (size_t)(threadIdx.x >> 6) * kRing * kRingFields;
+    float* const ring = reinterpret_cast<float*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * kRing * kRingFields;
     uint32_t ringHead = 0, pending = 0;
     unsigned int nEntriesOut = 0, nRadiance = 0;      // wave-uniform statistics (HrptStats queue-byte accounting)
+    // Sort by shading class (general variants). wf_extend left the class of the hit triangle's material in the hit record (0 constants only,
+    // 1 textured, 2 transmission branch; a miss counts as class 3: the sky lookup). When a segment is opened the wave counting-sorts its
+    // entries by class into a permutation in LDS (two passes over the 4-byte class words, ballot + prefix rank) and then shades the entries
+    // in that order, so that a 64-lane iteration holds one class (two at a class boundary) instead of a mix that runs every branch of
+    // shade_surface_a / miss_sky with a fraction of the lanes. Per path nothing changes: every path carries its RNG state and sample index,
+    // and survivors / NEE entries still compact into their own segment, only in another order.
+    constexpr bool SORT = !SIMPLE;
+    const uint32_t segSize = 1u << a.segShift;
+    uint16_t* const perm = reinterpret_cast<uint16_t*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * segSize;
+    uint8_t* const keys = reinterpret_cast<uint8_t*>(shadeSmem) + (size_t)wavesPerBlock * segSize * 2 + (size_t)uniform(threadIdx.x >> 6) * segSize;
+    bool permuted = false;
     // The wave works through its segments (gw, gw + totalWaves, ...) as one stream of 64-lane iterations: when the open segment A
     // has fewer than 64 entries left, the remaining lanes take the first entries of the next non-empty segment B, so only the wave's
     // last iteration is partially filled (after compaction a 256-slot segment holds ~207 / 168 / 136 paths at bounces 1 / 2 / 3: one
@@ -431,9 +452,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
         auto open_segment = [&]() {        // first non-empty segment at or after `seg`; empty ones get their (zero) counts written here
             haveSeg = false; cnt = 0; next = 0; outCount = 0; shCount = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = a.b.pathCnt[in][seg];
+                cnt = uniform(a.b.pathCnt[in][seg]);
                 if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
                 if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
+            }
+            if (SORT && a.sortShade && haveSeg) {
+                uint32_t c0 = 0, c1 = 0, c2 = 0;
+                for (uint32_t b = 0; b < cnt; b += 64) {
+                    const uint32_t e = b + lane; uint32_t k = 4u;
+                    if (e < cnt) { k = __float_as_uint(a.b.hit[segBase + e].w) >> 29; k = k > 3u ? 3u : k; keys[e] = (uint8_t)k; }
+                    c0 += (uint32_t)__popcll(__ballot(k == 0u)); c1 += (uint32_t)__popcll(__ballot(k == 1u)); c2 += (uint32_t)__popcll(__ballot(k == 2u));
+                }
+                const uint32_t c3 = cnt - c0 - c1 - c2;
+                permuted = !(c0 == cnt || c1 == cnt || c2 == cnt || c3 == cnt);      // a uniform segment is shaded in queue order
+                if (permuted) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    uint32_t b0 = 0, b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;
+                    for (uint32_t b = 0; b < cnt; b += 64) {
+                        const uint32_t e = b + lane; const uint32_t k = e < cnt ? keys[e] : 4u;
+                        const unsigned long long m0 = __ballot(k == 0u), m1 = __ballot(k == 1u), m2 = __ballot(k == 2u), m3 = __ballot(k == 3u);
+                        if (k == 0u) perm[b0 + prefix_rank(m0)] = (uint16_t)e;
+                        if (k == 1u) perm[b1 + prefix_rank(m1)] = (uint16_t)e;
+                        if (k == 2u) perm[b2 + prefix_rank(m2)] = (uint16_t)e;
+                        if (k == 3u) perm[b3 + prefix_rank(m3)] = (uint16_t)e;
+                        b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
             }
         };
         open_segment();
@@ -443,10 +488,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             const uint32_t segA = seg, baseA = segBase, nextA = next;
             const bool endsA = nextA + takeA >= cnt;
             uint32_t takeB = 0, segB = 0, baseB = 0, cntB = 0;
-            if (endsA && takeA < 64u) {
+            if (!SORT && endsA && takeA < 64u) {      // (a sorted segment is not mixed with its successor: the permutation is per segment)
                 uint32_t probe = seg + totalWaves;
                 for (; probe < a.numSegments; probe += totalWaves) {
-                    cntB = a.b.pathCnt[in][probe];
+                    cntB = uniform(a.b.pathCnt[in][probe]);
                     if (cntB) break;
                     if (lane == 0) { a.b.pathCnt[out][probe] = 0; a.b.shadowCnt[probe] = 0; }
                 }
@@ -462,9 +507,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             constexpr bool STREAMED = MAXL == 0;
             NeeBuf<(STREAMED ? 1 : MAXL)> nee; SurfaceCarry carry;
             if (valid) {
-                uint32_t slot = inA ? baseA + nextA + lane : baseB + (lane - takeA);
+                uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)perm[nextA + lane] : nextA + lane) : baseB + (lane - takeA);
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
+                if (tri != 0xFFFFFFFFu) tri &= 0x1FFFFFFFu;          // bits 29-31: shading class (wf_extend)
                 ps.ray.o = mk3(o.x, o.y, o.z); ps.ray.d = mk3(d.x, d.y, d.z); ps.ray.tmin = o.w; ps.ray.tmax = 1e10f;
                 ps.rng = __float_as_uint(d.w);
                 ps.throughput = mk3(t.x, t.y, t.z); smp = __float_as_uint(t.w);
@@ -601,7 +647,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                         if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
                         seg += totalWaves; open_segment();
                     }
-                } else if (takeA < 64u) { seg = segB; haveSeg = false; }     // probed to the end: nothing left
+                } else if (!SORT && takeA < 64u) { seg = segB; haveSeg = false; }     // probed to the end: nothing left
                 else { seg += totalWaves; open_segment(); }
             }
         }
@@ -618,9 +664,9 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
-    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift, items = cnt * a.maxLights;
+        const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg << a.segShift, items = cnt * a.maxLights;
         uint32_t outCount = 0;
         for (uint32_t i0 = 0; i0 < items; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -664,19 +710,19 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
 {
     constexpr bool NONOPAQUE = MODE != kShadowOpaque;
     constexpr int kLdsMax = MODE == kShadowResolve ? kExtendLdsStack : kShadowLdsStack;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kLdsMax> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = MODE == kShadowBuffered ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     if (DEPTH > kLdsMax) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
-    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kLdsMax>::kLds * kBlock * 4) + threadIdx.x;
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kLdsMax>::kRows * kBlock * 4) + threadIdx.x;
     typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
     const float sunIntensity = s.lights[0].m_Intensity;      // g_Lights[0], PathTracer.hlsl:137 (reference quirk kept)
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
-    const uint32_t gw = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), totalWaves = gridDim.x * wavesPerBlock;
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nRays = 0, nSamples = 0, nRadiance = 0;
     // one shadow-queue entry: every light sample of one path vertex
     auto process = [&](uint32_t e) {
@@ -741,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
         auto open_segment = [&]() {
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = a.b.shadowCnt[seg];
+                cnt = uniform(a.b.shadowCnt[seg]);
                 if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
             }
         };
@@ -758,7 +804,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
         }
     } else {
         for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-            const uint32_t cnt = a.b.shadowCnt[seg], segBase = seg << a.segShift;
+            const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg << a.segShift;
             for (uint32_t base = 0; base < cnt; base += 64) {
                 uint32_t i = base + lane;
                 if (i < cnt) process(segBase + i);
@@ -989,6 +1035,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.counters = counters;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
     a.streamSegments = st.drainSegments ? 0u : 1u;
+    a.sortShade = st.noShadeSort ? 0u : 1u;
 
     // ---- kernel variants and grids
     int dev = 0; hipDeviceProp_t prop;
@@ -1119,10 +1166,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
-            if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
-            else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)3 << a.segShift);      // per wave: uint16 permutation + uint8 class keys of one segment
+            if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
+            else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
-            else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), 0, stream, a, cb, parity, bounce, last);
+            else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
                 if ((e = hipEventRecord(st.forkEvents[(size_t)bounce], stream)) != hipSuccess || (e = hipStreamWaitEvent(st.auxStream, st.forkEvents[(size_t)bounce], 0)) != hipSuccess) { error = "fork to the shadow stream"; return e; }
