@@ -18,6 +18,31 @@
 
 #define HRT_DEV __device__ __forceinline__
 
+// Phase profile (make PHASES=1 builds libhobbyrt_pt_phases.so): HRT_PHASE(k) counts, per wave, how often a code region runs and with how
+// many lanes -- the lane utilisation of every stage of a kernel, which the PMC counters only give per kernel. One aggregated atomic per
+// wave and execution: slow, a diagnostic build only (scripts/phase_profile.py prints the table).
+#if defined(HRPT_PHASE_PROFILE) && defined(HRPT_PHASE_TU)       // only the wavefront translation unit is instrumented (no RDC)
+extern __device__ unsigned long long g_phaseCounters[128];
+#define HRT_PHASE(k)                                                                                                      \
+    do {                                                                                                                  \
+        const unsigned long long m_ = __ballot(true);                                                                     \
+        if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)m_) - 1)) {                                              \
+            atomicAdd(&g_phaseCounters[2 * (k)], 1ull); atomicAdd(&g_phaseCounters[2 * (k) + 1], (unsigned long long)__popcll(m_)); \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define HRT_PHASE(k) do { } while (0)
+#endif
+// phase ids
+enum {
+    PH_EXT_ITER = 0, PH_EXT_REFILL, PH_EXT_NODE, PH_EXT_LEAF, PH_EXT_TRI, PH_EXT_FINISH, PH_EXT_CANDIDATE,
+    PH_ANY_ITER = 8, PH_ANY_REFILL, PH_ANY_NODE, PH_ANY_LEAF, PH_ANY_TRI, PH_ANY_FINISH,
+    PH_SHADE_ITER = 16, PH_SHADE_HIT, PH_SHADE_ATTR, PH_SHADE_TEX, PH_SHADE_TRANS, PH_SHADE_NEE, PH_SHADE_LOBE_BEGIN, PH_SHADE_DIFFUSE, PH_SHADE_SPEC,
+    PH_SHADE_SKY, PH_SHADE_WRITE, PH_SHADE_SORT,
+    PH_SHADOW_ENTRY = 32, PH_SHADOW_SAMPLE, PH_SHADOW_QUERY, PH_SHADOW_CONTRIB, PH_SHADOW_RAYS_ITEM,
+    PH_COUNT = 40
+};
+
 namespace hrt {
 
 // ------------------------------------------------------------------ vectors
@@ -275,8 +300,9 @@ HRT_DEV f3 traversal_rcp(f3 d)
 // Closest triangle (opaque or not) with key strictly above `lower` (when lower.have) in (t, inst, prim) order.
 // while-while traversal: all lanes of the wave first descend inner nodes, then intersect leaves together.
 // STACK: per-lane traversal stack accessor (LDS column or private array).
+// nodeLoopMin: the descent loop ends once fewer lanes than this are still at inner nodes (thresholded while-while; 0 = run to a leaf)
 template <class BVH, class STACK>
-HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack)
+HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack, uint32_t nodeLoopMin = 0)
 {
     Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0; best.tri = 0;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
@@ -288,9 +314,12 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     else cur = 0;
     float tlim = r.tmax;               // == best.t once a hit exists
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+        while (cur >= 0) {
+            cur = inner_step(bvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+            if ((uint32_t)__popcll(__ballot(cur >= 0)) < nodeLoopMin) break;
+        }
         if (cur == kTraversalDone) break;
-        {
+        if (cur < 0) {
             uint32_t enc = (uint32_t)(~cur);
             uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
@@ -306,16 +335,16 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
                     }
                 }
             }
+            if (sp == 0) break;
+            cur = stack.pop(--sp);
         }
-        if (sp == 0) break;
-        cur = stack.pop(--sp);
     }
     return best;
 }
 
 // Any opaque-instance triangle in (tmin, tmax)? Early exit. Non-opaque triangles are only noted.
 template <class BVH, class STACK>
-HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, bool& sawNonOpaque)
+HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, bool& sawNonOpaque, uint32_t nodeLoopMin = 0)
 {
     sawNonOpaque = false;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
@@ -325,9 +354,12 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
     else cur = 0;
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, r.tmin, r.tmax, stack, sp);
+        while (cur >= 0) {
+            cur = inner_step(bvh, cur, noi, inv, r.tmin, r.tmax, stack, sp);
+            if ((uint32_t)__popcll(__ballot(cur >= 0)) < nodeLoopMin) break;
+        }
         if (cur == kTraversalDone) break;
-        {
+        if (cur < 0) {
             uint32_t enc = (uint32_t)(~cur);
             uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
@@ -338,9 +370,9 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
                     sawNonOpaque = true;
                 }
             }
+            if (sp == 0) break;
+            cur = stack.pop(--sp);
         }
-        if (sp == 0) break;
-        cur = stack.pop(--sp);
     }
     return false;
 }
@@ -787,6 +819,7 @@ HRT_DEV Pbr pbr_attributes(const SceneView& s, const SurfaceAttr& a, const HrptM
     Pbr p;
     p.baseColor = mk3(m.m_BaseColor); p.alpha = m.m_BaseColor[3];
     if (texFlags & HRPT_TEXFLAG_ALBEDO) {
+        HRT_PHASE(PH_SHADE_TEX);
         f4 t = sample_texture(s, m.m_AlbedoTextureIndex, m.m_AlbedoSamplerIndex, a.uv);
         p.baseColor = p.baseColor * mk3(t.x, t.y, t.z); p.alpha *= t.w;
     }

@@ -129,12 +129,12 @@ HRT_DEV Ray shadow_ray(f3 worldPos, f3 L, float maxDist)                        
 
 // Re-trace form: one closest-hit query per non-opaque candidate (validation megakernel).
 template <class BVH, class STACK>
-HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack)
+HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, uint32_t nodeLoopMin = 0)
 {
     Ray ray = shadow_ray(worldPos, L, maxDist);
     // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
     bool sawNonOpaque;
-    if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque)) return 0.0f;
+    if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque, nodeLoopMin)) return 0.0f;
     if (!sawNonOpaque) return 1.0f;
     ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
     HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
@@ -204,7 +204,7 @@ HRT_DEV float shadow_resolve_candidates(const SceneView& s, const BVH& bvh, cons
     return shadow_finish(ray, st);
 }
 template <int K, class BVH, class STACK, class CAND>
-HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, CAND& cand)
+HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, CAND& cand, uint32_t nodeLoopMin = 0)
 {
     Ray ray = shadow_ray(worldPos, L, maxDist);
     if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
@@ -214,8 +214,12 @@ HRT_DEV float shadow_query_buffered(const SceneView& s, const BVH& bvh, f3 world
     int32_t cur;
     if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
     for (;;) {
-        while (cur >= 0) cur = inner_step(bvh, cur, noi, inv, ray.tmin, ray.tmax, stack, sp);
+        while (cur >= 0) {
+            cur = inner_step(bvh, cur, noi, inv, ray.tmin, ray.tmax, stack, sp);
+            if ((uint32_t)__popcll(__ballot(cur >= 0)) < nodeLoopMin) break;
+        }
         if (cur == kTraversalDone) break;
+        if (cur >= 0) continue;
         uint32_t enc = (uint32_t)(~cur);
         uint32_t first = enc >> 2, n = (enc & 3u) + 1u;
         for (uint32_t i = 0; i < n; ++i) {
@@ -364,7 +368,9 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     in.roughness = pbr.roughness; in.metallic = pbr.metallic; in.ior = mat.m_IOR;
     prepare_byproducts(in);                                                       // :142 (L = 0 => H = V)
 
+    HRT_PHASE(PH_SHADE_ATTR);
     if (TRANS && (mat.m_TransmissionFactor > 0.0f || mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND)) {    // :149-255
+        HRT_PHASE(PH_SHADE_TRANS);
         float effectiveAlpha = (mat.m_AlphaMode == HRPT_ALPHA_MODE_BLEND) ? pbr.alpha : 1.0f;
         float transmissionFactor = hrt_max(mat.m_TransmissionFactor, 1.0f - effectiveAlpha);
         float materialIOR = hrt_max(mat.m_IOR, 1.0001f);
@@ -412,6 +418,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;
     carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic; carry.ior = mat.m_IOR;
     carry.rngBeforeLights = ps.rng;
+    HRT_PHASE(PH_SHADE_NEE);
     for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
         HrptGPULight l = load_light(s, i);
         float ux, uy;
@@ -430,6 +437,7 @@ struct LobeDraw { float specProb, root, sp, cp; bool spec; };
 
 HRT_DEV bool lobe_begin(PathState& ps, const SurfaceCarry& c, int bounce, LobeDraw& ld)
 {
+    HRT_PHASE(PH_SHADE_LOBE_BEGIN);
     if (bounce >= 2) {                                                            // Russian roulette :264-270
         float continuePr = hrt_saturate(maxcomp(ps.throughput));
         if (hrt_rng_next(&ps.rng) > continuePr) return false;
@@ -453,12 +461,14 @@ HRT_DEV bool lobe_finish(PathState& ps, f3 worldPos, f3 N, f3 newDir, f3 numer, 
 }
 HRT_DEV bool lobe_diffuse(PathState& ps, f3 worldPos, f3 N, f3 baseColor, float metallic, const LobeDraw& ld)
 {
+    HRT_PHASE(PH_SHADE_DIFFUSE);
     f3 T, B; tangent_frame(N, T, B);
     f3 newDir = sample_hemisphere_cosine_from(ld.root, ld.sp, ld.cp, T, B, N);
     return lobe_finish(ps, worldPos, N, newDir, baseColor * (1.0f - metallic), 1.0f - ld.specProb);
 }
 HRT_DEV bool lobe_specular(PathState& ps, f3 worldPos, f3 N, f3 V, f3 F0, float roughness, const LobeDraw& ld)
 {
+    HRT_PHASE(PH_SHADE_SPEC);
     f3 T, B; tangent_frame(N, T, B);
     f3 H = sample_ggx_vndf_from(ld.root, ld.sp, ld.cp, T, B, N, V, roughness);
     f3 newDir = reflect(-V, H);
@@ -475,6 +485,7 @@ HRT_DEV bool shade_surface_b(PathState& ps, const SurfaceCarry& c, int bounce)
 // PathTracer.hlsl:315-328
 HRT_DEV void miss_sky(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, int bounce)
 {
+    HRT_PHASE(PH_SHADE_SKY);
     f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
     f3 sky = atm::sky_radiance(s, ps.ray.o, ps.ray.d, sunDir, s.lights[0].m_Intensity, bounce == 0);
     ps.radiance = ps.radiance + ps.throughput * sky;

@@ -56,6 +56,7 @@ struct WavefrontState {
     uint32_t padLdsBytes = 0;          // experiment: extra dynamic LDS per trace block (lowers occupancy)
     uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
+    uint32_t nodeLoopMin = ~0u;        // HRPT_WF_NODE_LOOP_MIN: the descent loops end when fewer lanes than this are at inner nodes (~0 = automatic, 0 = never)
     bool noShadeSort = false;          // HRPT_WF_SHADE_SORT=0: general wf_shade variants shade in queue order (A/B knob)
     int shadowPath = 0;                // scenes with non-opaque geometry: 0 = automatic, 1 = wf_shadow traverses itself (buffered query), 2 = any-hit pass + resolve
 };

@@ -20,12 +20,17 @@
 // grid of persistent waves striding over segments; each wave reaches its exit when the segment index runs out.
 // The BVH (nodes + world-space triangles) is copied to LDS when it fits, and the traversal stack lives in LDS,
 // one column per lane (conflict-free), sized from the builder's maximum depth.
+#define HRPT_PHASE_TU 1
 #include "pt_wavefront.h"
 
 #include <vector>
 
 #include "bvh_build.h"
 #include "pt_path.h"
+
+#ifdef HRPT_PHASE_PROFILE
+__device__ unsigned long long g_phaseCounters[128];
+#endif
 
 namespace hrt {
 
@@ -66,6 +71,7 @@ struct WfArgs {
     uint32_t hasStochasticAlpha;
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
+    uint32_t nodeLoopMin;      // wf_extend leaves its node-descent loop once fewer lanes than this are still at inner nodes (0: never)
     uint32_t sortShade;        // wf_shade (general variants) shades the entries of a segment grouped by shading class
     int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
     DeviceCounters* counters;
@@ -317,9 +323,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
             // ---- refill idle lanes
             unsigned long long mIdle = __ballot(!active);
             uint32_t nIdle = (uint32_t)__popcll(mIdle);
+            if (active) HRT_PHASE(ANYHIT ? PH_ANY_ITER : PH_EXT_ITER);
             if (haveSeg && (nIdle >= a.refillMin || nIdle == 64u)) {
                 const uint32_t idx = next + prefix_rank(mIdle);
                 if (!active && idx < cnt) {
+                    HRT_PHASE(ANYHIT ? PH_ANY_REFILL : PH_EXT_REFILL);
                     slot = segBase + idx;
                     float4 o = rayO[slot], d = rayD[slot];
                     r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = ANYHIT ? d.w : 1e10f;
@@ -337,15 +345,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
             if (__ballot(active) == 0ull) { if (haveSeg) continue; break; }
             if (active) {
                 // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
+                // (the descent is cut short once fewer than nodeLoopMin lanes are still at inner nodes: the rest of the wave holds leaves and
+                // would only wait; the lanes cut off keep their node and go on in the next round. Thresholded while-while.)
                 while (cur >= 0) {
+                    HRT_PHASE(ANYHIT ? PH_ANY_NODE : PH_EXT_NODE);
                     if (LDS_BVH) cur = inner_step(lbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
                     else cur = inner_step(gbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+                    if ((uint32_t)__popcll(__ballot(cur >= 0)) < a.nodeLoopMin) break;
                 }
                 // ---- intersect the leaf
-                if (cur != kTraversalDone) {
+                if (cur < 0 && cur != kTraversalDone) {
                     uint32_t enc = (uint32_t)(~cur);
                     uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
+                    HRT_PHASE(ANYHIT ? PH_ANY_LEAF : PH_EXT_LEAF);
                     for (uint32_t i = 0; i < count; ++i) {
+                        HRT_PHASE(ANYHIT ? PH_ANY_TRI : PH_EXT_TRI);
                         float4 ta, tb, tc;
                         if (LDS_BVH) lbvh.tri(first + i, ta, tb, tc); else gbvh.tri(first + i, ta, tb, tc);
                         float t, u, v;
@@ -370,6 +384,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                 // ---- traversal finished: candidate resolution (TraceRayStandard) and hit record
                 if (ANYHIT) {
                     if (cur == kTraversalDone) {
+                        HRT_PHASE(PH_ANY_FINISH);
                         const uint32_t id = a.b.sqId[slot];
                         uint32_t code = blocked ? kVisBlocked : kVisClear;
                         if (!blocked && candCount > 0) {
@@ -382,6 +397,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                     }
                 } else if (cur == kTraversalDone) {
                     bool done = true;
+                    HRT_PHASE(PH_EXT_FINISH);
+                    if (best.valid && !(best.opaque & 1u)) HRT_PHASE(PH_EXT_CANDIDATE);
                     if (best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
                         // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
                         lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
@@ -457,6 +474,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
             }
             if (SORT && a.sortShade && haveSeg) {
+                HRT_PHASE(PH_SHADE_SORT);
                 uint32_t c0 = 0, c1 = 0, c2 = 0;
                 for (uint32_t b = 0; b < cnt; b += 64) {
                     const uint32_t e = b + lane; uint32_t k = 4u;
@@ -507,6 +525,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             constexpr bool STREAMED = MAXL == 0;
             NeeBuf<(STREAMED ? 1 : MAXL)> nee; SurfaceCarry carry;
             if (valid) {
+                HRT_PHASE(PH_SHADE_ITER);
                 uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)perm[nextA + lane] : nextA + lane) : baseB + (lane - takeA);
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
@@ -521,6 +540,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 } else { ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); ps.interiorIOR = 1.0f; ps.inVolume = false; }
                 bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
                 if (tri != 0xFFFFFFFFu) {
+                    HRT_PHASE(PH_SHADE_HIT);
                     Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
                     SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t li, float ux, float uy) {
@@ -560,6 +580,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             // ---- wave-local compaction of survivors into the out queue of their own segment
             const unsigned long long mA = __ballot(alive && inA), mB = __ballot(alive && !inA);
             if (alive) {
+                HRT_PHASE(PH_SHADE_WRITE);
                 uint32_t o = inA ? baseA + outCount + prefix_rank(mA) : baseB + prefix_rank(mB);
                 a.b.rayO[out][o] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tmin);
                 a.b.rayD[out][o] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.rng));
@@ -672,6 +693,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
             const uint32_t i = i0 + lane;
             bool valid = false; Ray ray; uint32_t id = 0;
             if (i < items) {
+                HRT_PHASE(PH_SHADOW_RAYS_ITEM);
                 const uint32_t el = i / a.maxLights, j = i - el * a.maxLights, e = segBase + el;
                 id = e * a.maxLights + j;
                 float4 h4 = a.b.sh4[e];
@@ -726,12 +748,14 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
     unsigned int nRays = 0, nSamples = 0, nRadiance = 0;
     // one shadow-queue entry: every light sample of one path vertex
     auto process = [&](uint32_t e) {
+                HRT_PHASE(PH_SHADOW_ENTRY);
                 float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], h4 = a.b.sh4[e];
                 f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), T = mk3(h4.x, h4.y, h4.z);
                 uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
                 nSamples += n;
                 f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f), totalSpecular = mk3(0.0f, 0.0f, 0.0f);
                 for (uint32_t j = 0; j < n; ++j) {
+                    HRT_PHASE(PH_SHADOW_SAMPLE);
                     uint32_t vis = kVisCandidates;
                     if (MODE == kShadowResolve) {
                         // outcome of the opaque any-hit pass (wf_shadow_rays + wf_extend<ANYHIT>): most rays are settled there
@@ -744,6 +768,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     f3 L; float maxDist;
                     if (!nee_direction<DIRONLY>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ls.x, ls.y, L, maxDist)) continue;
                     float shadow;
+                    HRT_PHASE(PH_SHADOW_QUERY);
                     if (MODE == kShadowResolve) {
                         if (vis == kVisClear) shadow = 1.0f;                             // no triangle at all in (tmin, tmax)
                         else {                                                           // the non-opaque triangles it crossed, nearest first
@@ -754,6 +779,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                             else shadow = shadow_resolve_candidates(s, gbvh, sr, make_shear(sr.d), cnt, ovf, gc, stack);
                         }
                     } else if (MODE == kShadowBuffered) {
+                        // (no descent threshold here: without lane refill it only costs: config 2 shadow +3 %, config 4 +2.5 %)
                         if (LDS_BVH) shadow = shadow_query_buffered<kShadowCandidates>(s, lbvh, origin, L, maxDist, stack, cand);
                         else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
                     } else {
@@ -762,6 +788,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     }
                     ++nRays;
                     if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped
+                        HRT_PHASE(PH_SHADOW_CONTRIB);
                         float4 h2 = a.b.sh2[e], h3 = a.b.sh3[e];
                         f3 dif, spec;
                         nee_contribution<DIRONLY>(s, l, nee_lighting(N, mk3(h2.x, h2.y, h2.z), mk3(h3.x, h3.y, h3.z), h1.w, h2.w, h3.w), origin, sunDir,
@@ -921,6 +948,17 @@ void wavefront_collect_timing(WavefrontState& st)
     st.eventsUsed = 0;
 }
 
+#ifdef HRPT_PHASE_PROFILE
+// reads (and zeroes) the phase counters of this library build
+extern "C" int hrpt_phase_profile_read(unsigned long long* out128)
+{
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_phaseCounters), 128 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    static const unsigned long long zero[128] = { 0 };
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phaseCounters), zero, sizeof zero) != hipSuccess) return -3;
+    return 0;
+}
+#endif
+
 void wavefront_reset_timing(WavefrontState& st)
 {
     st.eventsUsed = 0;
@@ -1036,6 +1074,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
     a.streamSegments = st.drainSegments ? 0u : 1u;
     a.sortShade = st.noShadeSort ? 0u : 1u;
+    a.nodeLoopMin = 0;      // set below, once the traversal variant is known
 
     // ---- kernel variants and grids
     int dev = 0; hipDeviceProp_t prop;
@@ -1077,6 +1116,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const Variant vA = pick(forced ? forced : 4, (size_t)kShadowCandidates * 2 * kBlock * 4, kExtendLdsStack);
     if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
     st.layout.shadowMode = shadowMode;
+    // Thresholded while-while (measured, scripts/env_sweep.sh HRPT_WF_NODE_LOOP_MIN): 16 lanes for an LDS-resident tree (config 2 extend -3 %),
+    // 24 for a tree in global memory (config 4 extend -11 %, glass config extend -24 % and its any-hit pass -14 %)
+    a.nodeLoopMin = st.nodeLoopMin != ~0u ? st.nodeLoopMin : (vE.lds ? 16u : 24u);
     // more blocks than fit: the dispatcher back-fills CUs as blocks retire (scripts/knob_sweep.py). A context that is one lane of a
     // two-frames-in-flight loop (hrpt_set_shadow_overlap(ctx, 0)) and traverses a tree in global memory does better with half the grid:
     // its latency-bound kernels leave room for the other lane's (config 4 14.4 -> 14.0 ms, config 5 22.6 -> 21.9 ms per frame).
