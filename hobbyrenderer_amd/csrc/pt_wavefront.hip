@@ -455,9 +455,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
     // and survivors / NEE entries still compact into their own segment, only in another order.
     constexpr bool SORT = !SIMPLE;
     const uint32_t segSize = 1u << a.segShift;
-    uint16_t* const perm = reinterpret_cast<uint16_t*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * segSize;
-    uint8_t* const keys = reinterpret_cast<uint8_t*>(shadeSmem) + (size_t)wavesPerBlock * segSize * 2 + (size_t)uniform(threadIdx.x >> 6) * segSize;
-    bool permuted = false;
+    // two permutation tables per wave (the open segment A and its successor B, which fills the lanes A's last iteration leaves empty) + keys
+    uint16_t* const permBase = reinterpret_cast<uint16_t*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * segSize * 2;
+    uint8_t* const keys = reinterpret_cast<uint8_t*>(shadeSmem) + (size_t)wavesPerBlock * segSize * 4 + (size_t)uniform(threadIdx.x >> 6) * segSize;
+    uint32_t permSel = 0;                      // which of the two tables belongs to segment A
+    bool permuted = false, permutedB = false;
+    // counting sort of the `n` entries of the segment at `base` by shading class into `perm`; false when the segment is uniform (queue order kept)
+    auto sort_segment = [&](uint32_t base, uint32_t n, uint16_t* perm) -> bool {
+        HRT_PHASE(PH_SHADE_SORT);
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t e = b + lane; uint32_t k = 4u;
+            if (e < n) { k = __float_as_uint(a.b.hit[base + e].w) >> 29; k = k > 3u ? 3u : k; keys[e] = (uint8_t)k; }
+            c0 += (uint32_t)__popcll(__ballot(k == 0u)); c1 += (uint32_t)__popcll(__ballot(k == 1u)); c2 += (uint32_t)__popcll(__ballot(k == 2u));
+        }
+        const uint32_t c3 = n - c0 - c1 - c2;
+        if (c0 == n || c1 == n || c2 == n || c3 == n) return false;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint32_t b0 = 0, b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t e = b + lane; const uint32_t k = e < n ? keys[e] : 4u;
+            const unsigned long long m0 = __ballot(k == 0u), m1 = __ballot(k == 1u), m2 = __ballot(k == 2u), m3 = __ballot(k == 3u);
+            if (k == 0u) perm[b0 + prefix_rank(m0)] = (uint16_t)e;
+            if (k == 1u) perm[b1 + prefix_rank(m1)] = (uint16_t)e;
+            if (k == 2u) perm[b2 + prefix_rank(m2)] = (uint16_t)e;
+            if (k == 3u) perm[b3 + prefix_rank(m3)] = (uint16_t)e;
+            b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        return true;
+    };
     // The wave works through its segments (gw, gw + totalWaves, ...) as one stream of 64-lane iterations: when the open segment A
     // has fewer than 64 entries left, the remaining lanes take the first entries of the next non-empty segment B, so only the wave's
     // last iteration is partially filled (after compaction a 256-slot segment holds ~207 / 168 / 136 paths at bounces 1 / 2 / 3: one
@@ -473,31 +500,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
                 if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
             }
-            if (SORT && a.sortShade && haveSeg) {
-                HRT_PHASE(PH_SHADE_SORT);
-                uint32_t c0 = 0, c1 = 0, c2 = 0;
-                for (uint32_t b = 0; b < cnt; b += 64) {
-                    const uint32_t e = b + lane; uint32_t k = 4u;
-                    if (e < cnt) { k = __float_as_uint(a.b.hit[segBase + e].w) >> 29; k = k > 3u ? 3u : k; keys[e] = (uint8_t)k; }
-                    c0 += (uint32_t)__popcll(__ballot(k == 0u)); c1 += (uint32_t)__popcll(__ballot(k == 1u)); c2 += (uint32_t)__popcll(__ballot(k == 2u));
-                }
-                const uint32_t c3 = cnt - c0 - c1 - c2;
-                permuted = !(c0 == cnt || c1 == cnt || c2 == cnt || c3 == cnt);      // a uniform segment is shaded in queue order
-                if (permuted) {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    uint32_t b0 = 0, b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;
-                    for (uint32_t b = 0; b < cnt; b += 64) {
-                        const uint32_t e = b + lane; const uint32_t k = e < cnt ? keys[e] : 4u;
-                        const unsigned long long m0 = __ballot(k == 0u), m1 = __ballot(k == 1u), m2 = __ballot(k == 2u), m3 = __ballot(k == 3u);
-                        if (k == 0u) perm[b0 + prefix_rank(m0)] = (uint16_t)e;
-                        if (k == 1u) perm[b1 + prefix_rank(m1)] = (uint16_t)e;
-                        if (k == 2u) perm[b2 + prefix_rank(m2)] = (uint16_t)e;
-                        if (k == 3u) perm[b3 + prefix_rank(m3)] = (uint16_t)e;
-                        b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                }
-            }
+            if (SORT && a.sortShade && haveSeg) permuted = sort_segment(segBase, cnt, permBase + permSel * segSize);
         };
         open_segment();
         while (haveSeg) {
@@ -506,15 +509,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             const uint32_t segA = seg, baseA = segBase, nextA = next;
             const bool endsA = nextA + takeA >= cnt;
             uint32_t takeB = 0, segB = 0, baseB = 0, cntB = 0;
-            if (!SORT && endsA && takeA < 64u) {      // (a sorted segment is not mixed with its successor: the permutation is per segment)
+            if (endsA && takeA < 64u) {
                 uint32_t probe = seg + totalWaves;
                 for (; probe < a.numSegments; probe += totalWaves) {
                     cntB = uniform(a.b.pathCnt[in][probe]);
                     if (cntB) break;
                     if (lane == 0) { a.b.pathCnt[out][probe] = 0; a.b.shadowCnt[probe] = 0; }
                 }
-                if (probe < a.numSegments) { segB = probe; baseB = probe << a.segShift; takeB = cntB < 64u - takeA ? cntB : 64u - takeA; }
-                else segB = probe;          // no further segment: remembered so that the cursor below ends the loop
+                if (probe < a.numSegments) {
+                    segB = probe; baseB = probe << a.segShift; takeB = cntB < 64u - takeA ? cntB : 64u - takeA;
+                    if (SORT && a.sortShade) permutedB = sort_segment(baseB, cntB, permBase + (permSel ^ 1u) * segSize);
+                } else segB = probe;          // no further segment: remembered so that the cursor below ends the loop
             }
             const bool inA = lane < takeA;
             uint32_t outCountB = 0, shCountB = 0;
@@ -526,7 +531,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             NeeBuf<(STREAMED ? 1 : MAXL)> nee; SurfaceCarry carry;
             if (valid) {
                 HRT_PHASE(PH_SHADE_ITER);
-                uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)perm[nextA + lane] : nextA + lane) : baseB + (lane - takeA);
+                uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)permBase[permSel * segSize + nextA + lane] : nextA + lane)
+                                    : baseB + ((SORT && permutedB) ? (uint32_t)permBase[(permSel ^ 1u) * segSize + (lane - takeA)] : lane - takeA);
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
                 if (tri != 0xFFFFFFFFu) tri &= 0x1FFFFFFFu;          // bits 29-31: shading class (wf_extend)
@@ -664,11 +670,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                     seg = segB; segBase = baseB; cnt = cntB; next = takeB;
                     outCount = outCountB; shCount = shCountB;
                     haveSeg = true;
+                    if (SORT) { permSel ^= 1u; permuted = permutedB; permutedB = false; }
                     if (next >= cnt) {       // B was short enough to end in the same iteration
                         if (lane == 0) { a.b.pathCnt[out][seg] = outCount; a.b.shadowCnt[seg] = shCount; }
                         seg += totalWaves; open_segment();
                     }
-                } else if (!SORT && takeA < 64u) { seg = segB; haveSeg = false; }     // probed to the end: nothing left
+                } else if (takeA < 64u) { seg = segB; haveSeg = false; }     // probed to the end: nothing left
                 else { seg += totalWaves; open_segment(); }
             }
         }
@@ -1073,7 +1080,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.counters = counters;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
     a.streamSegments = st.drainSegments ? 0u : 1u;
-    a.sortShade = st.noShadeSort ? 0u : 1u;
+    // default: on for scenes that sample textures (the longest branch of shade_surface_a; Sponza-class config: same shade time, -15 % VALU
+    // instructions), off otherwise (glass config: the sort costs 3.5 % of wf_shade, its classes are too few per segment to fill iterations)
+    a.sortShade = st.shadeSort < 0 ? (traits.hasTextures ? 1u : 0u) : (uint32_t)st.shadeSort;
     a.nodeLoopMin = 0;      // set below, once the traversal variant is known
 
     // ---- kernel variants and grids
@@ -1208,7 +1217,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
-            const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)3 << a.segShift);      // per wave: uint16 permutation + uint8 class keys of one segment
+            const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
             if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
