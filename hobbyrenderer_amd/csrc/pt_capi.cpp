@@ -149,6 +149,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_SERIAL_SHADOW")) c->wf.serialShadow = atoi(e) != 0;
     if (const char* e = getenv("HRPT_WF_SHADOW_PATH")) c->wf.shadowPath = atoi(e);
     if (const char* e = getenv("HRPT_WF_SHADE_SORT")) c->wf.shadeSort = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("HRPT_WF_SLIM_SHADOW")) c->wf.noSlimShadow = atoi(e) == 0;
     if (const char* e = getenv("HRPT_WF_NODE_LOOP_MIN")) c->wf.nodeLoopMin = (uint32_t)atoi(e);
     *out = c;
     return HRPT_OK;

@@ -25,6 +25,7 @@ struct PathState {
 struct SurfaceCarry {
     f3 N, V, worldPos, baseColor, F0; float Fr, roughness, metallic, ior;
     uint32_t rngBeforeLights;      // RNG state at the top of the light loop (:260): lets a schedule replay the loop's draws
+    uint32_t material;             // index into the material constants
 };
 
 HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_t px, uint32_t py)
@@ -417,7 +418,7 @@ HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerC
 
     carry.N = N; carry.V = V; carry.worldPos = attr.worldPos; carry.baseColor = pbr.baseColor; carry.F0 = in.F0;
     carry.Fr = in.F.x; carry.roughness = pbr.roughness; carry.metallic = pbr.metallic; carry.ior = mat.m_IOR;
-    carry.rngBeforeLights = ps.rng;
+    carry.rngBeforeLights = ps.rng; carry.material = tv.material;
     HRT_PHASE(PH_SHADE_NEE);
     for (uint32_t i = 0; i < cb.m_LightCount; ++i) {                              // AccumulateDirectLighting :260
         HrptGPULight l = load_light(s, i);

@@ -57,6 +57,7 @@ struct WavefrontState {
     uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
     uint32_t nodeLoopMin = ~0u;        // HRPT_WF_NODE_LOOP_MIN: the descent loops end when fewer lanes than this are at inner nodes (~0 = automatic, 0 = never)
+    bool noSlimShadow = false;         // HRPT_WF_SLIM_SHADOW=0: the SIMPLE shade variant writes full 96-byte shadow-queue entries (A/B knob)
     int shadeSort = -1;                // HRPT_WF_SHADE_SORT = 0 / 1: general wf_shade variants shade in queue order / grouped by shading class (-1: automatic)
     int shadowPath = 0;                // scenes with non-opaque geometry: 0 = automatic, 1 = wf_shadow traverses itself (buffered query), 2 = any-hit pass + resolve
 };

@@ -71,6 +71,8 @@ struct WfArgs {
     uint32_t hasStochasticAlpha;
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
+    uint32_t slimShadow;       // slim shadow-queue entries (scenes of the SIMPLE shade variant with one light): sh0{origin, input slot} sh1{N, material}
+    uint32_t shadowParity;     // ... and the path queue those slots index (the input queue of the bounce's wf_shade)
     uint32_t nodeLoopMin;      // wf_extend leaves its node-descent loop once fewer lanes than this are still at inner nodes (0: never)
     uint32_t sortShade;        // wf_shade (general variants) shades the entries of a segment grouped by shading class
     int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             uint32_t outCountB = 0, shCountB = 0;
             bool valid = lane < takeA + takeB, alive = false, wantDefer = false, wantRadiance = false;
             LobeDraw ld; ld.spec = false; ld.specProb = 0.0f; ld.root = 0.0f; ld.sp = 0.0f; ld.cp = 0.0f;
-            uint32_t nNee = 0, smp = 0;
+            uint32_t nNee = 0, smp = 0, slotIn = 0;
             PathState ps; f3 neeT = mk3(0.0f, 0.0f, 0.0f);
             constexpr bool STREAMED = MAXL == 0;
             NeeBuf<(STREAMED ? 1 : MAXL)> nee; SurfaceCarry carry;
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 HRT_PHASE(PH_SHADE_ITER);
                 uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)permBase[permSel * segSize + nextA + lane] : nextA + lane)
                                     : baseB + ((SORT && permutedB) ? (uint32_t)permBase[(permSel ^ 1u) * segSize + (lane - takeA)] : lane - takeA);
+                slotIn = slot;
                 float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
                 if (tri != 0xFFFFFFFFu) tri &= 0x1FFFFFFFu;          // bits 29-31: shading class (wf_extend)
@@ -598,7 +601,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             }
             // ---- wave-local compaction of NEE work into the shadow queue of their own segment
             const unsigned long long msA = __ballot(nNee > 0 && inA), msB = __ballot(nNee > 0 && !inA);
-            if (nNee > 0) {
+            if (SIMPLE && MAXL == 1 && a.slimShadow && nNee > 0) {
+                // Slim entry (32 instead of 96 bytes): in a scene of this variant nothing is drawn before the light loop and the throughput
+                // is not touched before it, so wf_shadow takes V, the RNG state of the two draws, T and the sample index from the path's INPUT
+                // record (slotIn), and roughness / metallic / base colour / IOR from the material constants (no texture can modify them).
+                uint32_t e = inA ? baseA + shCount + prefix_rank(msA) : baseB + prefix_rank(msB);
+                a.b.sh0[e] = make_float4(carry.worldPos.x, carry.worldPos.y, carry.worldPos.z, __uint_as_float(slotIn));
+                a.b.sh1[e] = make_float4(carry.N.x, carry.N.y, carry.N.z, __uint_as_float(carry.material));
+            } else if (nNee > 0) {
                 uint32_t e = inA ? baseA + shCount + prefix_rank(msA) : baseB + prefix_rank(msB);
                 a.b.sh0[e] = make_float4(carry.worldPos.x, carry.worldPos.y, carry.worldPos.z, __uint_as_float(smp));
                 a.b.sh1[e] = make_float4(carry.N.x, carry.N.y, carry.N.z, carry.roughness);
@@ -733,11 +743,13 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
 // MODE kShadowBuffered: non-opaque geometry, the kernel traverses itself: per-lane candidate buffer in LDS (after the stack) and the buffered query.
 // MODE kShadowResolve: non-opaque geometry, visibility traversal already done by wf_shadow_rays + wf_extend<ANYHIT>: this kernel only walks
 //   the recorded candidate lists (its stack serves the rare re-trace behind an overflowing list) and evaluates the contributions.
-enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2 };
+// MODE kShadowSlim: kShadowOpaque with directional lights only and the 32-byte entries of wf_shade<1, SIMPLE> (see there).
+enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadowSlim = 3 };
 template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE>
 __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
-    constexpr bool NONOPAQUE = MODE != kShadowOpaque;
+    constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;
+    constexpr bool SLIM = MODE == kShadowSlim;
     constexpr int kLdsMax = MODE == kShadowResolve ? kExtendLdsStack : kShadowLdsStack;
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kLdsMax> stack; LdsBvh<W> lbvh;
@@ -756,6 +768,42 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
     // one shadow-queue entry: every light sample of one path vertex
     auto process = [&](uint32_t e) {
                 HRT_PHASE(PH_SHADOW_ENTRY);
+                if (SLIM) {
+                    const float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e];
+                    const uint32_t slot = __float_as_uint(h0.w);
+                    const float4 rd = a.b.rayD[a.shadowParity][slot];
+                    const f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
+                    uint32_t rng = __float_as_uint(rd.w);
+                    const float ux = hrt_rng_next(&rng), uy = hrt_rng_next(&rng);      // the two draws of nee_draw (CommonLighting.hlsli:730)
+                    ++nSamples;
+                    HrptGPULight l = load_light(s, 0u);
+                    f3 L; float maxDist;
+                    if (!nee_direction<true>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ux, uy, L, maxDist)) return;
+                    float shadow;
+                    if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
+                    else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
+                    ++nRays;
+                    if (shadow != 0.0f) {
+                        const float4 th = a.b.thr[a.shadowParity][slot];
+                        const HrptMaterialConstants& mat = s.materials[__float_as_uint(h1.w)];
+                        // GetPBRAttributes without textures (RaytracingCommon.hlsli:252-296): constants, roughness clamped at 0.04
+                        f3 dif, spec;
+                        nee_contribution<true>(s, l, nee_lighting(N, mk3(-rd.x, -rd.y, -rd.z), mk3(mat.m_BaseColor), hrt_max(mat.m_RoughnessMetallic[0], 0.04f),
+                                                                  mat.m_RoughnessMetallic[1], mat.m_IOR), origin, sunDir, sunIntensity, L, dif, spec);
+                        f3 totalDiffuse = mk3(0.0f, 0.0f, 0.0f) + dif * shadow, totalSpecular = mk3(0.0f, 0.0f, 0.0f);
+                        if (bounce == 0) totalSpecular = totalSpecular + spec * shadow;
+                        const f3 dsum = totalDiffuse + (bounce == 0 ? totalSpecular : mk3(0.0f, 0.0f, 0.0f));
+                        if (dsum.x != 0.0f || dsum.y != 0.0f || dsum.z != 0.0f) {
+                            const f3 term = mk3(th.x, th.y, th.z) * dsum;
+                            const uint32_t smp = __float_as_uint(th.w);
+                            float4 r = a.b.radiance[smp];
+                            r.x = r.x + term.x; r.y = r.y + term.y; r.z = r.z + term.z;
+                            a.b.radiance[smp] = r;
+                            ++nRadiance;
+                        }
+                    }
+                    return;
+                }
                 float4 h0 = a.b.sh0[e], h1 = a.b.sh1[e], h4 = a.b.sh4[e];
                 f3 origin = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), T = mk3(h4.x, h4.y, h4.z);
                 uint32_t smp = __float_as_uint(h0.w), n = __float_as_uint(h4.w);
@@ -892,7 +940,8 @@ template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStrea
     if (nonOpaque == kShadowResolve) hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowResolve>), g, dim3(kBlock), sh, st, a, cb, bounce);
     else if (nonOpaque == kShadowBuffered) {   // general variant (all light types) + candidate buffer
         hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowBuffered>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
-    } else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    } else if (nonOpaque == kShadowSlim) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowSlim>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
     else hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
@@ -984,6 +1033,10 @@ void wavefront_queue_bytes(const WavefrontState& st, const DeviceCounters& c, ui
     trace = c.closestRays * (32 + 16);
     shade = c.closestRays * (path + 16) + survivors * path + c.neeEntries * 80 + c.neeSamples * 16 + c.radianceShade * 32;
     shadow = c.neeEntries * 48 + c.neeSamples * 16 + c.radianceShadow * (32 + 32);
+    if (st.layout.shadowMode == kShadowSlim) {     // 32-byte entries; wf_shadow re-reads rayD (always) and thr (unoccluded samples) of the path's input record
+        shade = c.closestRays * (path + 16) + survivors * path + c.neeEntries * 32 + c.radianceShade * 32;
+        shadow = c.neeEntries * (32 + 16) + c.radianceShadow * (16 + 32);
+    }
     if (st.layout.shadowMode == kShadowResolve) shadow += c.neeEntries * 32 + c.neeSamples * 16 + c.shadowRays * 72 + c.neeEntries * st.layout.maxLights * 8;
 }
 
@@ -1124,6 +1177,12 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // (launch_extend_t adds them to the launch), opaque scene or not, so the budget check must count them too.
     const Variant vA = pick(forced ? forced : 4, (size_t)kShadowCandidates * 2 * kBlock * 4, kExtendLdsStack);
     if (shadowMode == kShadowResolve) vS = pick(forced ? forced : 4, 0, kExtendLdsStack);
+    const bool manyLightsEarly = maxLights > 1;
+    const bool simpleEarly = !traits.hasTextures && !traits.hasTransmissiveOrBlend && traits.directionalLightsOnly && !st.forceGeneralShade;
+    // slim shadow-queue entries: the SIMPLE single-light shade variant feeding the plain opaque any-hit query (HRPT_WF_SLIM_SHADOW=0 keeps the 96-byte entries)
+    const bool slim = simpleEarly && !manyLightsEarly && shadowMode == kShadowOpaque && !st.noSlimShadow;
+    if (slim) shadowMode = kShadowSlim;
+    a.slimShadow = slim ? 1u : 0u;
     st.layout.shadowMode = shadowMode;
     // Thresholded while-while (measured, scripts/env_sweep.sh HRPT_WF_NODE_LOOP_MIN): 16 lanes for an LDS-resident tree (config 2 extend -3 %),
     // 24 for a tree in global memory (config 4 extend -11 %, glass config extend -24 % and its any-hit pass -14 %)
@@ -1201,6 +1260,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         // NEE visibility + accumulation. With non-opaque geometry in the scene: ray generation, the opaque any-hit pass in the refilling
         // traversal kernel, then wf_shadow for the contributions and the (few) rays that crossed non-opaque triangles.
         auto shadow_stage = [&](hipStream_t sst, int bounce) {
+            a.shadowParity = (uint32_t)bounce & 1u;
             if (shadowMode == kShadowResolve) {
                 if (traits.directionalLightsOnly) hipLaunchKernelGGL((wf_shadow_rays<true>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
                 else hipLaunchKernelGGL((wf_shadow_rays<false>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
