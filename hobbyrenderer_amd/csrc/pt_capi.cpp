@@ -813,6 +813,25 @@ int hrpt_selftest_f16_decode(HrptContext* c, float* out65536)
     return HRPT_OK;
 }
 
+int hrpt_selftest_bvh(HrptContext* c, uint64_t* violations)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (!violations) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_selftest_bvh: null out");
+    if (!c->haveScene) return fail(c, HRPT_ERR_NO_SCENE, "hrpt_selftest_bvh: no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_bvh_check(c->view, d, c->stream);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, HRPT_ERR_HIP, std::string("hrpt_selftest_bvh: ") + hipGetErrorString(e));
+    *violations = h;
+    return HRPT_OK;
+}
+
 int hrpt_selftest_unorm8(HrptContext* c, float* out512)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;

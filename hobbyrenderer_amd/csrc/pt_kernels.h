@@ -42,6 +42,8 @@ hipError_t launch_post_chain(const float4* hdr, float4* display, uint32_t pixelC
 // Batch ray queries (hrpt_trace_rays): closest hit with the candidate rules of TraceRayStandard, or NEE-style visibility.
 hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRayHit* hits, uint64_t count, bool shadow, hipStream_t stream);
 
+// Self-test: counts child boxes of the 2-wide and 4-wide trees that do not contain their subtree's boxes / triangle vertices (0 = sound).
+hipError_t launch_bvh_check(const SceneView& scene, unsigned long long* violations, hipStream_t stream);
 // Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).
 hipError_t launch_unorm8_table(float* out512, hipStream_t stream);
 hipError_t launch_f16_table(float* out, hipStream_t stream);

@@ -153,6 +153,70 @@ hipError_t launch_f16_table(float* out, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Self-test of the acceleration structure (hrpt_selftest_bvh): every child box stored in a node must contain what hangs below it -- the
+// child's own child boxes when it is an inner node, the vertices of its triangles when it is a leaf. The GPU builder fits boxes bottom-up
+// with relaxed agent-scope atomics and write-through stores (bvh_build_gpu.hip k_fit); a stale read there would give a parent box that is
+// too small, i.e. silently missed hits, which image parity on a few scenes cannot rule out. One thread per node; violations are counted.
+__device__ __forceinline__ bool box_in(const float* mn, const float* mx, const float* cmn, const float* cmx)
+{
+    return cmn[0] >= mn[0] && cmn[1] >= mn[1] && cmn[2] >= mn[2] && cmx[0] <= mx[0] && cmx[1] <= mx[1] && cmx[2] <= mx[2];
+}
+__device__ __forceinline__ bool leaf_in(const SceneView& s, int32_t ref, const float* mn, const float* mx)
+{
+    const uint32_t enc = (uint32_t)(~ref), first = enc >> 2, count = (enc & 3u) + 1u;
+    bool ok = first + count <= s.triCount;
+    for (uint32_t i = 0; ok && i < count; ++i) {
+        const GpuTri& t = s.tris[first + i];
+        for (int k = 0; k < 3; ++k)
+            ok = ok && t.p0[k] >= mn[k] && t.p0[k] <= mx[k] && t.p1[k] >= mn[k] && t.p1[k] <= mx[k] && t.p2[k] >= mn[k] && t.p2[k] <= mx[k];
+    }
+    return ok;
+}
+__global__ void pt_bvh_check_kernel(SceneView s, unsigned long long* violations)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int bad = 0;
+    if (i < s.nodeCount) {                              // 2-wide tree
+        const GpuNode& n = s.nodes[i];
+        const float* mn[2] = { n.lmin, n.rmin }; const float* mx[2] = { n.lmax, n.rmax }; const int32_t ref[2] = { n.left, n.right };
+        for (int c = 0; c < 2; ++c) {
+            if (ref[c] >= 0) {
+                if ((uint32_t)ref[c] >= s.nodeCount) { ++bad; continue; }
+                const GpuNode& m = s.nodes[ref[c]];
+                if (!box_in(mn[c], mx[c], m.lmin, m.lmax) || !box_in(mn[c], mx[c], m.rmin, m.rmax)) ++bad;
+            } else if (!leaf_in(s, ref[c], mn[c], mx[c])) ++bad;
+        }
+    }
+    if (i < s.node4Count) {                             // its 4-wide collapse
+        const GpuNode4& n = s.nodes4[i];
+        const float* r[6] = { &n.minx.x, &n.miny.x, &n.minz.x, &n.maxx.x, &n.maxy.x, &n.maxz.x };
+        const int32_t* ch = &n.child.x;
+        for (int c = 0; c < 4; ++c) {
+            if (ch[c] == 0x7fffffff) continue;          // unused slot
+            const float mn[3] = { r[0][c], r[1][c], r[2][c] }, mx[3] = { r[3][c], r[4][c], r[5][c] };
+            if (ch[c] >= 0) {
+                if ((uint32_t)ch[c] >= s.node4Count) { ++bad; continue; }
+                const GpuNode4& m = s.nodes4[ch[c]];
+                const float* q[6] = { &m.minx.x, &m.miny.x, &m.minz.x, &m.maxx.x, &m.maxy.x, &m.maxz.x };
+                const int32_t* mch = &m.child.x;
+                for (int k = 0; k < 4; ++k) {
+                    if (mch[k] == 0x7fffffff) continue;
+                    const float cmn[3] = { q[0][k], q[1][k], q[2][k] }, cmx[3] = { q[3][k], q[4][k], q[5][k] };
+                    if (!box_in(mn, mx, cmn, cmx)) ++bad;
+                }
+            } else if (!leaf_in(s, ch[c], mn, mx)) ++bad;
+        }
+    }
+    if (bad) atomicAdd(violations, (unsigned long long)bad);
+}
+hipError_t launch_bvh_check(const SceneView& scene, unsigned long long* violations, hipStream_t stream)
+{
+    const uint32_t n = scene.nodeCount > scene.node4Count ? scene.nodeCount : scene.node4Count;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_bvh_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scene, violations);
+    return hipGetLastError();
+}
+
 // Stand-alone ray queries over the scene's acceleration structure: TraceRayStandard (RaytracingCommon.hlsli:138-198) and
 // CalculateRTShadow<true> (CommonLighting.hlsli:380-496) for callers other than the path tracer (the reference's DDGI probe trace,
 // ray-traced shadows and BRDF ray tracing share exactly these two includes). One thread per ray, 2-wide tree, private stack.

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -62,6 +62,7 @@ lib.hrpt_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_ui
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
 lib.hrpt_selftest_f16_decode.argtypes = [C.c_void_p, C.c_void_p]
 lib.hrpt_selftest_unorm8.argtypes = [C.c_void_p, C.c_void_p]
+lib.hrpt_selftest_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.hrpt_post_process.argtypes = [C.c_void_p, C.POINTER(S.PostParams)]
 lib.hrpt_read_display.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 lib.hrpt_get_exposure.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
@@ -248,6 +249,12 @@ class PathTracerContext:
         out = np.empty(65536, np.float32)
         self._check(lib.hrpt_selftest_f16_decode(self._h, out.ctypes.data))
         return out
+
+    def selftest_bvh(self):
+        """Number of child boxes of the acceleration structure that do not contain their subtree (0 = sound)."""
+        v = C.c_uint64()
+        self._check(lib.hrpt_selftest_bvh(self._h, C.byref(v)))
+        return int(v.value)
 
     def selftest_unorm8(self):
         out = np.empty(512, np.float32)

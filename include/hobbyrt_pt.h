@@ -403,6 +403,9 @@ int  hrpt_set_shadow_overlap(HrptContext* ctx, int enabled);
 
 int  hrpt_get_stats(HrptContext* ctx, HrptStats* out);      /* synchronises; ray counters are cumulative */
 int  hrpt_reset_stats(HrptContext* ctx);
+/* Device self-test of the acceleration structure: *violations = number of child boxes (2-wide tree and its 4-wide collapse) that do
+ * not contain the boxes / triangle vertices below them. 0 for a sound tree; anything else means missed hits. Synchronises. */
+int  hrpt_selftest_bvh(HrptContext* ctx, uint64_t* violations);
 /* Device self-test: out65536[i] = the kernels' decode of the binary16 bit pattern i (RGBA16F LUT texels). */
 int  hrpt_selftest_f16_decode(HrptContext* ctx, float* out65536);
 /* out512[i] = the kernels' RGBA8_UNORM channel decode of byte i (i < 256); out512[256 + i] = (float)i / 255.0f computed on the device. */

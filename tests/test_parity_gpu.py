@@ -438,6 +438,31 @@ def test_million_triangle_bvh(ctx, luts, flags):
     _assert_parity(*res)
 
 
+@pytest.mark.parametrize("builder", [S.BVH_BUILDER_GPU_LBVH, S.BVH_BUILDER_GPU_PLOC, S.BVH_BUILDER_HOST_SAH], ids=["lbvh", "ploc", "host"])
+def test_every_box_contains_its_subtree(luts, builder):
+    """The GPU builders fit boxes bottom-up across CUs with relaxed atomics and write-through stores (bvh_build_gpu.hip k_fit); a stale read
+    would leave a parent box too small -- silently missed hits. hrpt_selftest_bvh checks, on the device, that every child box of the 2-wide
+    tree and of its 4-wide collapse contains the boxes / triangle vertices below it: the 1.17 M-triangle scene (several rebuilds, since a
+    race would be intermittent), a mid-size one, and the host builder as the control."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(builder)
+        big = builder != S.BVH_BUILDER_HOST_SAH
+        sc, _, _, _ = scenes.config_sponza_class(luts, 96, 54, detail=3.4 if big else 1.0, tex_size=32)
+        c.upload_scene(sc)
+        assert c.stats().bvhTriangleCount > (1000000 if big else 50000)
+        assert c.selftest_bvh() == 0
+        if big:
+            for k in range(4):          # rebuilds with moved instances (the per-frame path of hrpt_update_instances)
+                inst = sc.instances.copy()
+                inst["m_World"][:, 3, 0] += 0.01 * (k + 1)      # row-vector convention: translation in row 3
+                c.update_instances(inst)
+                assert c.selftest_bvh() == 0, f"rebuild {k}"
+    finally:
+        c.close()
+
+
 def test_device_f16_decode_table(ctx):
     """The kernels decode RGBA16F LUT texels with the hardware conversion; it must equal the contract's integer decode
     (detmath.h hrt_f16tof32 == numpy) for every one of the 65536 encodings, subnormals included."""
