@@ -841,7 +841,7 @@ void LoadTexturesFromImages(Scene& scene, const std::filesystem::path& sceneDir)
             }
             t_warnings.push_back("texture " + std::to_string(i) + ": " + err + " -- decoded " + tex.m_SourceUri + " instead");
         }
-        tex.m_Pixels = std::move(img.rgba); tex.m_Width = img.width; tex.m_Height = img.height;
+        tex.m_Pixels = std::move(img.rgba); tex.m_Width = img.width; tex.m_Height = img.height; tex.m_Format = img.format; tex.m_MipCount = img.mipCount;
         tex.m_BindlessIndex = next++;
     }
     // a material whose texture did not load goes back to "no texture" for that slot, so the default-texture indices apply

@@ -262,59 +262,226 @@ void bc_alpha_block(const uint8_t* blk, uint8_t a[16])
 }
 }
 
+// ---- BC7 (D3D11 functional spec 19.5.x / the BPTC specification): 8 modes, 1-3 subsets, 64 partitions, optional p-bits, channel rotation
+namespace {
+const uint8_t kBc7Partition2[64][16] = {
+    {0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1},{0,0,0,1,0,0,0,1,0,0,0,1,0,0,0,1},{0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1},{0,0,0,1,0,0,1,1,0,0,1,1,0,1,1,1},
+    {0,0,0,0,0,0,0,1,0,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,1,0,1,1,1,1,1,1,1},{0,0,0,1,0,0,1,1,0,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,1,0,0,1,1,0,1,1,1},
+    {0,0,0,0,0,0,0,0,0,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,1,0,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,0,0,0,1,0,1,1,1},
+    {0,0,0,1,0,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1},{0,0,0,0,1,1,1,1,1,1,1,1,1,1,1,1},{0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1},
+    {0,0,0,0,1,0,0,0,1,1,1,0,1,1,1,1},{0,1,1,1,0,0,0,1,0,0,0,0,0,0,0,0},{0,0,0,0,0,0,0,0,1,0,0,0,1,1,1,0},{0,1,1,1,0,0,1,1,0,0,0,1,0,0,0,0},
+    {0,0,1,1,0,0,0,1,0,0,0,0,0,0,0,0},{0,0,0,0,1,0,0,0,1,1,0,0,1,1,1,0},{0,0,0,0,0,0,0,0,1,0,0,0,1,1,0,0},{0,1,1,1,0,0,1,1,0,0,1,1,0,0,0,1},
+    {0,0,1,1,0,0,0,1,0,0,0,1,0,0,0,0},{0,0,0,0,1,0,0,0,1,0,0,0,1,1,0,0},{0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0},{0,0,1,1,0,1,1,0,0,1,1,0,1,1,0,0},
+    {0,0,0,1,0,1,1,1,1,1,1,0,1,0,0,0},{0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0},{0,1,1,1,0,0,0,1,1,0,0,0,1,1,1,0},{0,0,1,1,1,0,0,1,1,0,0,1,1,1,0,0},
+    {0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},{0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1},{0,1,0,1,1,0,1,0,0,1,0,1,1,0,1,0},{0,0,1,1,0,0,1,1,1,1,0,0,1,1,0,0},
+    {0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0},{0,1,0,1,0,1,0,1,1,0,1,0,1,0,1,0},{0,1,1,0,1,0,0,1,0,1,1,0,1,0,0,1},{0,1,0,1,1,0,1,0,1,0,1,0,0,1,0,1},
+    {0,1,1,1,0,0,1,1,1,1,0,0,1,1,1,0},{0,0,0,1,0,0,1,1,1,1,0,0,1,0,0,0},{0,0,1,1,0,0,1,0,0,1,0,0,1,1,0,0},{0,0,1,1,1,0,1,1,1,1,0,1,1,1,0,0},
+    {0,1,1,0,1,0,0,1,1,0,0,1,0,1,1,0},{0,0,1,1,1,1,0,0,1,1,0,0,0,0,1,1},{0,1,1,0,0,1,1,0,1,0,0,1,1,0,0,1},{0,0,0,0,0,1,1,0,0,1,1,0,0,0,0,0},
+    {0,1,0,0,1,1,1,0,0,1,0,0,0,0,0,0},{0,0,1,0,0,1,1,1,0,0,1,0,0,0,0,0},{0,0,0,0,0,0,1,0,0,1,1,1,0,0,1,0},{0,0,0,0,0,1,0,0,1,1,1,0,0,1,0,0},
+    {0,1,1,0,1,1,0,0,1,0,0,1,0,0,1,1},{0,0,1,1,0,1,1,0,1,1,0,0,1,0,0,1},{0,1,1,0,0,0,1,1,1,0,0,1,1,1,0,0},{0,0,1,1,1,0,0,1,1,1,0,0,0,1,1,0},
+    {0,1,1,0,1,1,0,0,1,1,0,0,1,0,0,1},{0,1,1,0,0,0,1,1,0,0,1,1,1,0,0,1},{0,1,1,1,1,1,1,0,1,0,0,0,0,0,0,1},{0,0,0,1,1,0,0,0,1,1,1,0,0,1,1,1},
+    {0,0,0,0,1,1,1,1,0,0,1,1,0,0,1,1},{0,0,1,1,0,0,1,1,1,1,1,1,0,0,0,0},{0,0,1,0,0,0,1,0,1,1,1,0,1,1,1,0},{0,1,0,0,0,1,0,0,0,1,1,1,0,1,1,1} };
+const uint8_t kBc7Partition3[64][16] = {
+    {0,0,1,1,0,0,1,1,0,2,2,1,2,2,2,2},{0,0,0,1,0,0,1,1,2,2,1,1,2,2,2,1},{0,0,0,0,2,0,0,1,2,2,1,1,2,2,1,1},{0,2,2,2,0,0,2,2,0,0,1,1,0,1,1,1},
+    {0,0,0,0,0,0,0,0,1,1,2,2,1,1,2,2},{0,0,1,1,0,0,1,1,0,0,2,2,0,0,2,2},{0,0,2,2,0,0,2,2,1,1,1,1,1,1,1,1},{0,0,1,1,0,0,1,1,2,2,1,1,2,2,1,1},
+    {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2},{0,0,0,0,1,1,1,1,1,1,1,1,2,2,2,2},{0,0,0,0,1,1,1,1,2,2,2,2,2,2,2,2},{0,0,1,2,0,0,1,2,0,0,1,2,0,0,1,2},
+    {0,1,1,2,0,1,1,2,0,1,1,2,0,1,1,2},{0,1,2,2,0,1,2,2,0,1,2,2,0,1,2,2},{0,0,1,1,0,1,1,2,1,1,2,2,1,2,2,2},{0,0,1,1,2,0,0,1,2,2,0,0,2,2,2,0},
+    {0,0,0,1,0,0,1,1,0,1,1,2,1,1,2,2},{0,1,1,1,0,0,1,1,2,0,0,1,2,2,0,0},{0,0,0,0,1,1,2,2,1,1,2,2,1,1,2,2},{0,0,2,2,0,0,2,2,0,0,2,2,1,1,1,1},
+    {0,1,1,1,0,1,1,1,0,2,2,2,0,2,2,2},{0,0,0,1,0,0,0,1,2,2,2,1,2,2,2,1},{0,0,0,0,0,0,1,1,0,1,2,2,0,1,2,2},{0,0,0,0,1,1,0,0,2,2,1,0,2,2,1,0},
+    {0,1,2,2,0,1,2,2,0,0,1,1,0,0,0,0},{0,0,1,2,0,0,1,2,1,1,2,2,2,2,2,2},{0,1,1,0,1,2,2,1,1,2,2,1,0,1,1,0},{0,0,0,0,0,1,1,0,1,2,2,1,1,2,2,1},
+    {0,0,2,2,1,1,0,2,1,1,0,2,0,0,2,2},{0,1,1,0,0,1,1,0,2,0,0,2,2,2,2,2},{0,0,1,1,0,1,2,2,0,1,2,2,0,0,1,1},{0,0,0,0,2,0,0,0,2,2,1,1,2,2,2,1},
+    {0,0,0,0,0,0,0,2,1,1,2,2,1,2,2,2},{0,2,2,2,0,0,2,2,0,0,1,2,0,0,1,1},{0,0,1,1,0,0,1,2,0,0,2,2,0,2,2,2},{0,1,2,0,0,1,2,0,0,1,2,0,0,1,2,0},
+    {0,0,0,0,1,1,1,1,2,2,2,2,0,0,0,0},{0,1,2,0,1,2,0,1,2,0,1,2,0,1,2,0},{0,1,2,0,2,0,1,2,1,2,0,1,0,1,2,0},{0,0,1,1,2,2,0,0,1,1,2,2,0,0,1,1},
+    {0,0,1,1,1,1,2,2,2,2,0,0,0,0,1,1},{0,1,0,1,0,1,0,1,2,2,2,2,2,2,2,2},{0,0,0,0,0,0,0,0,2,1,2,1,2,1,2,1},{0,0,2,2,1,1,2,2,0,0,2,2,1,1,2,2},
+    {0,0,2,2,0,0,1,1,0,0,2,2,0,0,1,1},{0,2,2,0,1,2,2,1,0,2,2,0,1,2,2,1},{0,1,0,1,2,2,2,2,2,2,2,2,0,1,0,1},{0,0,0,0,2,1,2,1,2,1,2,1,2,1,2,1},
+    {0,1,0,1,0,1,0,1,0,1,0,1,2,2,2,2},{0,2,2,2,0,1,1,1,0,2,2,2,0,1,1,1},{0,0,0,2,1,1,1,2,0,0,0,2,1,1,1,2},{0,0,0,0,2,1,1,2,2,1,1,2,2,1,1,2},
+    {0,2,2,2,0,1,1,1,0,1,1,1,0,2,2,2},{0,0,0,2,1,1,1,2,1,1,1,2,0,0,0,2},{0,1,1,0,0,1,1,0,0,1,1,0,2,2,2,2},{0,0,0,0,0,0,0,0,2,1,1,2,2,1,1,2},
+    {0,1,1,0,0,1,1,0,2,2,2,2,2,2,2,2},{0,0,2,2,0,0,1,1,0,0,1,1,0,0,2,2},{0,0,2,2,1,1,2,2,1,1,2,2,0,0,2,2},{0,0,0,0,0,0,0,0,0,0,0,0,2,1,1,2},
+    {0,0,0,2,0,0,0,1,0,0,0,2,0,0,0,1},{0,2,2,2,1,2,2,2,0,2,2,2,1,2,2,2},{0,1,0,1,2,2,2,2,2,2,2,2,2,2,2,2},{0,1,1,1,2,0,1,1,2,2,0,1,2,2,2,0} };
+const uint8_t kBc7Anchor2[64] = { 15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15, 15,2,8,2,2,8,8,15, 2,8,2,2,8,8,2,2, 15,15,6,8,2,8,15,15, 2,8,2,2,2,15,15,6, 6,2,6,8,15,15,2,2, 15,15,15,15,15,2,2,15 };
+const uint8_t kBc7Anchor3a[64] = { 3,3,15,15,8,3,15,15, 8,8,6,6,6,5,3,3, 3,3,8,15,3,3,6,10, 5,8,8,6,8,5,15,15, 8,15,3,5,6,10,8,15, 15,3,15,5,15,15,15,15, 3,15,5,5,5,8,5,10, 5,10,8,13,15,12,3,3 };
+const uint8_t kBc7Anchor3b[64] = { 15,8,8,3,15,15,3,8, 15,15,15,15,15,15,15,8, 15,8,15,3,15,8,15,8, 3,15,6,10,15,15,10,8, 15,3,15,10,10,8,9,10, 6,15,8,15,3,6,6,8, 15,3,15,15,15,15,15,15, 15,15,15,15,3,15,15,8 };
+const uint8_t kBcWeights2[4] = { 0, 21, 43, 64 }, kBcWeights3[8] = { 0, 9, 18, 27, 37, 46, 55, 64 }, kBcWeights4[16] = { 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64 };
+struct Bc7Mode { uint8_t ns, pb, rb, isb, cb, ab, epb, spb, ib, ib2; };
+const Bc7Mode kBc7Modes[8] = { {3,4,0,0,4,0,1,0,3,0}, {2,6,0,0,6,0,0,1,3,0}, {3,6,0,0,5,0,0,0,2,0}, {2,6,0,0,7,0,1,0,2,0},
+                               {1,0,2,1,5,6,0,0,2,3}, {1,0,2,0,7,8,0,0,2,2}, {1,0,0,0,7,7,1,0,4,0}, {2,6,0,0,5,5,1,0,2,0} };
+struct BitReader {
+    const uint8_t* p; uint32_t pos = 0;
+    uint32_t get(uint32_t n) { uint32_t v = 0; for (uint32_t i = 0; i < n; ++i, ++pos) v |= (uint32_t)((p[pos >> 3] >> (pos & 7)) & 1u) << i; return v; }
+};
+inline const uint8_t* bc_weights(uint32_t bits) { return bits == 2 ? kBcWeights2 : (bits == 3 ? kBcWeights3 : kBcWeights4); }
+void bc7_block(const uint8_t* blk, uint8_t px[16][4])
+{
+    uint32_t mode = 0; while (mode < 8 && !((blk[0] >> mode) & 1)) ++mode;
+    if (mode == 8) { std::memset(px, 0, 64); return; }        // reserved mode: transparent black (spec)
+    const Bc7Mode& m = kBc7Modes[mode];
+    BitReader br{ blk, mode + 1 };
+    const uint32_t partition = br.get(m.pb), rotation = br.get(m.rb), indexSel = br.get(m.isb);
+    const uint32_t ne = m.ns * 2u;
+    uint32_t e[6][4];                                         // endpoints [subset * 2 + {0, 1}][r, g, b, a]
+    for (int c = 0; c < 3; ++c) for (uint32_t i = 0; i < ne; ++i) e[i][c] = br.get(m.cb);
+    for (uint32_t i = 0; i < ne; ++i) e[i][3] = m.ab ? br.get(m.ab) : 255u;
+    uint32_t cbits = m.cb, abits = m.ab;
+    if (m.epb) { for (uint32_t i = 0; i < ne; ++i) { const uint32_t p = br.get(1); for (int c = 0; c < 3; ++c) e[i][c] = (e[i][c] << 1) | p; if (m.ab) e[i][3] = (e[i][3] << 1) | p; } ++cbits; if (m.ab) ++abits; }
+    if (m.spb) { for (uint32_t sub = 0; sub < m.ns; ++sub) { const uint32_t p = br.get(1); for (uint32_t k = 0; k < 2; ++k) for (int c = 0; c < 3; ++c) e[sub * 2 + k][c] = (e[sub * 2 + k][c] << 1) | p; } ++cbits; }
+    for (uint32_t i = 0; i < ne; ++i) {
+        for (int c = 0; c < 3; ++c) { const uint32_t v = e[i][c] << (8 - cbits); e[i][c] = v | (v >> cbits); }
+        if (m.ab) { const uint32_t v = e[i][3] << (8 - abits); e[i][3] = v | (v >> abits); }
+    }
+    uint8_t subsetOf[16];
+    for (int i = 0; i < 16; ++i) subsetOf[i] = m.ns == 1 ? 0 : (m.ns == 2 ? kBc7Partition2[partition][i] : kBc7Partition3[partition][i]);
+    uint32_t anchor[3] = { 0, 0, 0 };
+    if (m.ns == 2) anchor[1] = kBc7Anchor2[partition];
+    if (m.ns == 3) { anchor[1] = kBc7Anchor3a[partition]; anchor[2] = kBc7Anchor3b[partition]; }
+    uint32_t idx1[16], idx2[16];
+    for (uint32_t i = 0; i < 16; ++i) { const bool isAnchor = i == anchor[subsetOf[i]]; idx1[i] = br.get(isAnchor ? m.ib - 1u : m.ib); }
+    for (uint32_t i = 0; i < 16; ++i) idx2[i] = m.ib2 ? br.get(i == 0 ? m.ib2 - 1u : m.ib2) : 0;
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t* e0 = e[subsetOf[i] * 2], * e1 = e[subsetOf[i] * 2 + 1];
+        uint32_t ci = idx1[i], cbw = m.ib, ai = idx1[i], abw = m.ib;
+        if (m.ib2) { if (indexSel) { ci = idx2[i]; cbw = m.ib2; } else { ai = idx2[i]; abw = m.ib2; } }
+        const uint32_t wc = bc_weights(cbw)[ci], wa = bc_weights(abw)[ai];
+        uint32_t c[4];
+        for (int k = 0; k < 3; ++k) c[k] = ((64 - wc) * e0[k] + wc * e1[k] + 32) >> 6;
+        c[3] = ((64 - wa) * e0[3] + wa * e1[3] + 32) >> 6;
+        if (rotation == 1) std::swap(c[3], c[0]); else if (rotation == 2) std::swap(c[3], c[1]); else if (rotation == 3) std::swap(c[3], c[2]);
+        for (int k = 0; k < 4; ++k) px[i][k] = (uint8_t)c[k];
+    }
+}
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline void put_f32(std::vector<uint8_t>& v, size_t texel, const float rgba[4]) { std::memcpy(&v[texel * 16], rgba, 16); }
+// one channel of a BC4_SNORM / BC5_SNORM block: signed endpoints, palette interpolated in float (D3D11 functional spec 19.5.7)
+void bc_alpha_block_snorm(const uint8_t* blk, float a[16])
+{
+    const int r0 = (int8_t)blk[0], r1 = (int8_t)blk[1];
+    const float f0 = r0 == -128 ? -1.0f : (float)r0 / 127.0f, f1 = r1 == -128 ? -1.0f : (float)r1 / 127.0f;
+    float e[8]; e[0] = f0; e[1] = f1;
+    if (r0 > r1) for (int i = 1; i < 7; ++i) e[1 + i] = ((float)(7 - i) * f0 + (float)i * f1) / 7.0f;
+    else { for (int i = 1; i < 5; ++i) e[1 + i] = ((float)(5 - i) * f0 + (float)i * f1) / 5.0f; e[6] = -1.0f; e[7] = 1.0f; }
+    uint64_t bits = 0; for (int i = 0; i < 6; ++i) bits |= (uint64_t)blk[2 + i] << (8 * i);
+    for (int i = 0; i < 16; ++i) a[i] = e[(bits >> (3 * i)) & 7];
+}
+}
+bool Bc7TablesConsistent()
+{   // every anchor index must lie in the subset it anchors (a transcription check of the partition / anchor tables against each other)
+    for (int p = 0; p < 64; ++p) {
+        if (kBc7Partition2[p][0] != 0 || kBc7Partition2[p][kBc7Anchor2[p]] != 1) return false;
+        if (kBc7Partition3[p][0] != 0 || kBc7Partition3[p][kBc7Anchor3a[p]] != 1 || kBc7Partition3[p][kBc7Anchor3b[p]] != 2) return false;
+    }
+    return true;
+}
+
+// DDS: the header walk and format map of src/TextureLoader.cpp:66-213 (GetFormatFromDDS); every level of the file is decoded.
 bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
 {
     if (n < 128 || std::memcmp(d, "DDS ", 4) != 0 || le32(d + 4) != 124) { err = "not a DDS file"; return false; }
-    uint32_t h = le32(d + 12), w = le32(d + 16), pfFlags = le32(d + 80), fourCC = le32(d + 84), bitCount = le32(d + 88);
+    uint32_t h = le32(d + 12), w = le32(d + 16), mipMapCount = le32(d + 28), pfFlags = le32(d + 80), fourCC = le32(d + 84), bitCount = le32(d + 88);
     uint32_t rm = le32(d + 92), gm = le32(d + 96), bm = le32(d + 100), am = le32(d + 104);
     size_t off = 128; uint32_t dxgi = 0;
     const bool hasFourCC = (pfFlags & 0x4) != 0;
     if (hasFourCC && fourCC == 0x30315844u /* "DX10" */) { if (n < 148) { err = "DDS DX10 header truncated"; return false; } dxgi = le32(d + 128); off = 148; }
     if (w == 0 || h == 0 || w > 32768 || h > 32768) { err = "bad DDS dimensions"; return false; }
-    enum { RGBA8, BGRA8, BC1, BC2, BC3, BC4, BC5 } fmt;
+    enum Fmt { RGBA8, BGRA8, BC1, BC2, BC3, BC4U, BC4S, BC5U, BC5S, BC7, R16F, RG16F, RGBA16F, R32F, RG32F, RGBA32F, RG16U, RGBA16U } fmt;
+    bool srgb = false;
     if (dxgi) {
-        switch (dxgi) { case 28: case 29: fmt = RGBA8; break; case 71: case 72: fmt = BC1; break; case 74: case 75: fmt = BC2; break; case 77: case 78: fmt = BC3; break;
-                        case 80: fmt = BC4; break; case 83: fmt = BC5; break; default: err = "unsupported DXGI format " + std::to_string(dxgi) + " (BC6H/BC7 and float formats are not decoded on the host)"; return false; }
+        switch (dxgi) {
+            case 28: fmt = RGBA8; break; case 29: fmt = RGBA8; srgb = true; break; case 34: fmt = RG16F; break; case 35: fmt = RG16U; break;
+            case 71: fmt = BC1; break; case 72: fmt = BC1; srgb = true; break; case 74: fmt = BC2; break; case 75: fmt = BC2; srgb = true; break;
+            case 77: fmt = BC3; break; case 78: fmt = BC3; srgb = true; break; case 80: fmt = BC4U; break; case 81: fmt = BC4S; break;
+            case 83: fmt = BC5U; break; case 84: fmt = BC5S; break; case 98: fmt = BC7; break; case 99: fmt = BC7; srgb = true; break;
+            case 95: case 96: err = "DXGI format " + std::to_string(dxgi) + " (BC6H) is not decoded on the host"; return false;
+            default: err = "unsupported DXGI format " + std::to_string(dxgi); return false;
+        }
     } else if (hasFourCC) {
         if (fourCC == 0x31545844u) fmt = BC1; else if (fourCC == 0x33545844u) fmt = BC2; else if (fourCC == 0x35545844u) fmt = BC3;
-        else if (fourCC == 0x31495441u) fmt = BC4; else if (fourCC == 0x32495441u) fmt = BC5; else { err = "unsupported DDS FourCC"; return false; }
+        else if (fourCC == 0x31495441u) fmt = BC4U; else if (fourCC == 0x32495441u) fmt = BC5U;
+        else if (fourCC == 34) fmt = RG16U; else if (fourCC == 36) fmt = RGBA16U; else if (fourCC == 111) fmt = R16F; else if (fourCC == 112) fmt = RG16F;
+        else if (fourCC == 113) fmt = RGBA16F; else if (fourCC == 114) fmt = R32F; else if (fourCC == 115) fmt = RG32F; else if (fourCC == 116) fmt = RGBA32F;
+        else { err = "unsupported DDS FourCC"; return false; }
     } else if ((pfFlags & 0x40) && bitCount == 32 && rm == 0x00ff0000u && gm == 0x0000ff00u && bm == 0x000000ffu && am == 0xff000000u) fmt = BGRA8;   // the reference labels this mask set RGBA8_UNORM (:118-121); the bytes in memory are B,G,R,A
     else if ((pfFlags & 0x40) && bitCount == 32 && rm == 0x000000ffu && gm == 0x0000ff00u && bm == 0x00ff0000u && am == 0xff000000u) fmt = RGBA8;
     else { err = "unsupported DDS pixel format"; return false; }
-    out.width = w; out.height = h; out.rgba.assign((size_t)w * h * 4, 255);
-    const uint8_t* p = d + off; size_t left = n - off;
-    if (fmt == RGBA8 || fmt == BGRA8) {
-        if (left < (size_t)w * h * 4) { err = "DDS pixel data truncated"; return false; }
-        for (size_t i = 0; i < (size_t)w * h; ++i) { const uint8_t* s = p + 4 * i; uint8_t* o = &out.rgba[4 * i]; if (fmt == RGBA8) std::memcpy(o, s, 4); else { o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; o[3] = s[3]; } }
-        return true;
+    uint32_t levels = mipMapCount ? mipMapCount : 1u;            // desc.mipLevels = dwMipMapCount ? dwMipMapCount : 1 (:202)
+    uint32_t maxLevels = 1; while ((w >> maxLevels) || (h >> maxLevels)) ++maxLevels;
+    if (levels > maxLevels || levels > 16u) { err = "DDS mip count exceeds the chain of a " + std::to_string(w) + "x" + std::to_string(h) + " texture"; return false; }
+    const bool blockFmt = fmt >= BC1 && fmt <= BC7;
+    const bool toF16 = fmt == R16F || fmt == RG16F || fmt == RGBA16F;
+    const bool toF32 = fmt == R32F || fmt == RG32F || fmt == RGBA32F || fmt == RG16U || fmt == RGBA16U || fmt == BC4S || fmt == BC5S;
+    const size_t texelBytes = toF32 ? 16 : (toF16 ? 8 : 4);
+    out.format = toF32 ? 3u : (toF16 ? 2u : (srgb ? 1u : 0u));
+    // payload size first: nothing is allocated for a truncated file
+    size_t need = 0, totalTexels = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+        const size_t lw = std::max(1u, w >> l), lh = std::max(1u, h >> l);
+        totalTexels += lw * lh;
+        if (blockFmt) need += ((lw + 3) / 4) * ((lh + 3) / 4) * ((fmt == BC1 || fmt == BC4U || fmt == BC4S) ? 8 : 16);
+        else { const size_t srcBytes = fmt == RGBA8 || fmt == BGRA8 ? 4 : (fmt == R16F ? 2 : (fmt == RG16F || fmt == R32F || fmt == RG16U ? 4 : (fmt == RGBA16F || fmt == RG32F || fmt == RGBA16U ? 8 : 16))); need += lw * lh * srcBytes; }
     }
-    const size_t bw = (w + 3) / 4, bh = (h + 3) / 4, blockBytes = (fmt == BC1 || fmt == BC4) ? 8 : 16;
-    if (left < bw * bh * blockBytes) { err = "DDS block data truncated"; return false; }
-    for (size_t by = 0; by < bh; ++by) for (size_t bx = 0; bx < bw; ++bx) {
-        const uint8_t* blk = p + (by * bw + bx) * blockBytes;
-        uint8_t px[16][4];
-        if (fmt == BC1 || fmt == BC2 || fmt == BC3) {
-            const uint8_t* cblk = fmt == BC1 ? blk : blk + 8;
-            uint8_t pal[4][4]; bc1_colors(cblk, pal, fmt == BC1);
-            uint32_t idx = le32(cblk + 4);
-            for (int i = 0; i < 16; ++i) std::memcpy(px[i], pal[(idx >> (2 * i)) & 3], 4);
-            if (fmt == BC2) for (int i = 0; i < 16; ++i) { uint32_t a4 = (blk[i >> 1] >> ((i & 1) * 4)) & 15; px[i][3] = (uint8_t)(a4 * 17); }
-            if (fmt == BC3) { uint8_t a[16]; bc_alpha_block(blk, a); for (int i = 0; i < 16; ++i) px[i][3] = a[i]; }
+    if (n - off < need) { err = "DDS pixel data truncated"; return false; }
+    out.width = w; out.height = h; out.mipCount = levels; out.rgba.assign(totalTexels * texelBytes, 0);
+    const uint8_t* p = d + off; size_t texelBase = 0;
+    const uint16_t halfOne = 0x3C00u;
+    for (uint32_t l = 0; l < levels; ++l) {
+        const size_t lw = std::max(1u, w >> l), lh = std::max(1u, h >> l);
+        if (!blockFmt) {
+            for (size_t i = 0; i < lw * lh; ++i) {
+                const size_t t = texelBase + i;
+                if (fmt == RGBA8) { std::memcpy(&out.rgba[t * 4], p, 4); p += 4; }
+                else if (fmt == BGRA8) { uint8_t* o = &out.rgba[t * 4]; o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; o[3] = p[3]; p += 4; }
+                else if (toF16) {
+                    uint16_t v[4] = { 0, 0, 0, halfOne }; const int nc = fmt == R16F ? 1 : (fmt == RG16F ? 2 : 4);
+                    for (int c = 0; c < nc; ++c) v[c] = le16(p + 2 * c);
+                    std::memcpy(&out.rgba[t * 8], v, 8); p += 2 * nc;
+                } else if (fmt == RG16U || fmt == RGBA16U) {
+                    float v[4] = { 0.0f, 0.0f, 0.0f, 1.0f }; const int nc = fmt == RG16U ? 2 : 4;
+                    for (int c = 0; c < nc; ++c) v[c] = (float)le16(p + 2 * c) / 65535.0f;
+                    put_f32(out.rgba, t, v); p += 2 * nc;
+                } else {
+                    float v[4] = { 0.0f, 0.0f, 0.0f, 1.0f }; const int nc = fmt == R32F ? 1 : (fmt == RG32F ? 2 : 4);
+                    std::memcpy(v, p, 4 * (size_t)nc); put_f32(out.rgba, t, v); p += 4 * nc;
+                }
+            }
         } else {
-            uint8_t r[16], g[16]; bc_alpha_block(blk, r);
-            if (fmt == BC5) bc_alpha_block(blk + 8, g);
-            for (int i = 0; i < 16; ++i) { px[i][0] = r[i]; px[i][1] = fmt == BC5 ? g[i] : 0; px[i][2] = 0; px[i][3] = 255; }
+            const size_t bw = (lw + 3) / 4, bh = (lh + 3) / 4, blockBytes = (fmt == BC1 || fmt == BC4U || fmt == BC4S) ? 8 : 16;
+            for (size_t by = 0; by < bh; ++by) for (size_t bx = 0; bx < bw; ++bx) {
+                const uint8_t* blk = p + (by * bw + bx) * blockBytes;
+                uint8_t px[16][4]; float pf[16][4];
+                if (fmt == BC1 || fmt == BC2 || fmt == BC3) {
+                    const uint8_t* cblk = fmt == BC1 ? blk : blk + 8;
+                    uint8_t pal[4][4]; bc1_colors(cblk, pal, fmt == BC1);
+                    uint32_t idx = le32(cblk + 4);
+                    for (int i = 0; i < 16; ++i) std::memcpy(px[i], pal[(idx >> (2 * i)) & 3], 4);
+                    if (fmt == BC2) for (int i = 0; i < 16; ++i) { uint32_t a4 = (blk[i >> 1] >> ((i & 1) * 4)) & 15; px[i][3] = (uint8_t)(a4 * 17); }
+                    if (fmt == BC3) { uint8_t a[16]; bc_alpha_block(blk, a); for (int i = 0; i < 16; ++i) px[i][3] = a[i]; }
+                } else if (fmt == BC7) bc7_block(blk, px);
+                else if (fmt == BC4U || fmt == BC5U) {
+                    uint8_t r[16], g[16]; bc_alpha_block(blk, r);
+                    if (fmt == BC5U) bc_alpha_block(blk + 8, g);
+                    for (int i = 0; i < 16; ++i) { px[i][0] = r[i]; px[i][1] = fmt == BC5U ? g[i] : 0; px[i][2] = 0; px[i][3] = 255; }
+                } else {
+                    float r[16], g[16]; bc_alpha_block_snorm(blk, r);
+                    if (fmt == BC5S) bc_alpha_block_snorm(blk + 8, g);
+                    for (int i = 0; i < 16; ++i) { pf[i][0] = r[i]; pf[i][1] = fmt == BC5S ? g[i] : 0.0f; pf[i][2] = 0.0f; pf[i][3] = 1.0f; }
+                }
+                for (int i = 0; i < 16; ++i) {
+                    const size_t x = bx * 4 + (i & 3), y = by * 4 + (i >> 2);
+                    if (x >= lw || y >= lh) continue;
+                    if (toF32) put_f32(out.rgba, texelBase + y * lw + x, pf[i]); else std::memcpy(&out.rgba[(texelBase + y * lw + x) * 4], px[i], 4);
+                }
+            }
+            p += bw * bh * blockBytes;
         }
-        for (int i = 0; i < 16; ++i) { size_t x = bx * 4 + (i & 3), y = by * 4 + (i >> 2); if (x < w && y < h) std::memcpy(&out.rgba[(y * w + x) * 4], px[i], 4); }
+        texelBase += lw * lh;
     }
     return true;
 }
 
 
-// ------------------------------------------------------------------ JPEG (baseline / extended sequential Huffman, 8 bit)
+// ------------------------------------------------------------------ JPEG (baseline / extended sequential / progressive Huffman, 8 bit)
 // Integer pipeline as in stb_image (public domain, not in the reference tree; the reference decodes through it): 12-bit fixed-point
 // inverse DCT of the jidctint family, triangle-filter chroma upsampling for 2x1 / 1x2 / 2x2, 20-bit fixed-point YCbCr -> RGB.
-// Progressive and arithmetic-coded files, 12-bit samples and CMYK are reported as unsupported.
+// Progressive files keep the coefficients of every block over their scans (spectral selection + successive approximation, T.81 annex G)
+// and are transformed at the end. Arithmetic-coded files, 12-bit samples and CMYK are reported as unsupported.
 namespace {
 const uint8_t kDezigzag[64 + 15] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
                                      29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };
@@ -408,7 +575,8 @@ void jidct_block(uint8_t* out, size_t stride, const short d[64])
         o[2] = jclamp((x2 + t1) >> 17); o[5] = jclamp((x2 - t1) >> 17); o[3] = jclamp((x3 + t0) >> 17); o[4] = jclamp((x3 - t0) >> 17);
     }
 }
-struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dcPred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data; };
+struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dcPred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data;
+               std::vector<short> coeff; };      // progressive: the coefficients of every block (64 each, natural order), refined scan by scan
 // one output row of a component at full resolution
 void jresample(const JComp& c, int hs, int vs, const uint8_t* nearRow, const uint8_t* farRow, int wLores, uint8_t* out)
 {
@@ -442,7 +610,7 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
     if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) { err = "not a JPEG"; return false; }
     uint16_t quant[4][64]; bool haveQuant[4] = { false, false, false, false };
     JHuff dcTab[4], acTab[4];
-    std::vector<JComp> comps; int width = 0, height = 0, hmax = 1, vmax = 1, restart = 0, adobeTransform = -1; bool sawSOF = false, decoded = false;
+    std::vector<JComp> comps; int width = 0, height = 0, hmax = 1, vmax = 1, restart = 0, adobeTransform = -1; bool sawSOF = false, decoded = false, progressive = false;
     size_t pos = 2;
     auto u16 = [&](size_t o) { return (int)((data[o] << 8) | data[o + 1]); };
     while (pos + 4 <= n) {
@@ -475,8 +643,9 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
             }
         } else if (m == 0xDD) { if (sl < 2) { err = "bad DRI"; return false; } restart = (seg[0] << 8) | seg[1]; }
         else if (m == 0xEE && sl >= 12 && !std::memcmp(seg, "Adobe", 5)) adobeTransform = seg[11];
-        else if (m == 0xC0 || m == 0xC1) {
+        else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (sawSOF) { err = "JPEG with several frames"; return false; }
+            progressive = m == 0xC2;
             if (sl < 6 || seg[0] != 8) { err = "only 8-bit JPEG samples are supported"; return false; }
             height = (seg[1] << 8) | seg[2]; width = (seg[3] << 8) | seg[4]; int nc = seg[5];
             if (width <= 0 || height <= 0 || width > 32768 || height > 32768) { err = "bad JPEG dimensions"; return false; }
@@ -493,9 +662,10 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
             for (JComp& c : comps) {
                 c.x = (width * c.h + hmax - 1) / hmax; c.y = (height * c.v + vmax - 1) / vmax; c.w2 = mcuX * c.h * 8; c.h2 = mcuY * c.v * 8;
                 c.data.assign((size_t)c.w2 * c.h2 + 15, 0);
+                if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
             }
             sawSOF = true;
-        } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) { err = m == 0xC2 ? "progressive JPEG is not supported (re-save as baseline, or use PNG / DDS)" : "unsupported JPEG coding process"; return false; }
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) { err = "unsupported JPEG coding process (lossless, hierarchical or arithmetic)"; return false; }
         else if (m == 0xDA) {
             if (!sawSOF || sl < 1) { err = "SOS before SOF"; return false; }
             int ns = seg[0];
@@ -505,12 +675,69 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
                 JComp* c = nullptr; for (JComp& k : comps) if (k.id == seg[1 + 2 * i]) c = &k;
                 if (!c) { err = "SOS names an unknown component"; return false; }
                 c->td = seg[2 + 2 * i] >> 4; c->ta = seg[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !dcTab[c->td].ok || !acTab[c->ta].ok || !haveQuant[c->tq]) { err = "scan uses an undefined table"; return false; }
+                if (c->td > 3 || c->ta > 3 || !haveQuant[c->tq]) { err = "scan uses an undefined table"; return false; }
                 scan.push_back(c);
             }
-            if (seg[1 + 2 * ns] != 0 || seg[2 + 2 * ns] != 63) { err = "spectral selection in a sequential JPEG"; return false; }
+            const int specStart = seg[1 + 2 * ns], specEnd = seg[2 + 2 * ns], succHigh = seg[3 + 2 * ns] >> 4, succLow = seg[3 + 2 * ns] & 15;
+            if (!progressive) {
+                if (specStart != 0 || specEnd != 63) { err = "spectral selection in a sequential JPEG"; return false; }
+                for (JComp* c : scan) if (!dcTab[c->td].ok || !acTab[c->ta].ok) { err = "scan uses an undefined table"; return false; }
+            } else {
+                if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13 || (specStart == 0 && specEnd != 0) || (specStart > 0 && ns != 1)) { err = "bad progressive scan parameters"; return false; }
+                for (JComp* c : scan) if (specStart == 0 ? (succHigh == 0 && !dcTab[c->td].ok) : !acTab[c->ta].ok) { err = "scan uses an undefined table"; return false; }
+            }
             JBits bits{ data + pos + (size_t)len, data + n };
             for (JComp& c : comps) c.dcPred = 0;
+            int eobRun = 0;
+            // one block of a progressive scan (ITU T.81 annex G; the decode order of stb_image's stbi__jpeg_decode_block_prog_dc / _ac)
+            auto block_prog = [&](JComp& c, int bx, int by) -> bool {
+                short* dat = c.coeff.data() + 64 * ((size_t)bx + (size_t)by * (size_t)(c.w2 >> 3));
+                if (specStart == 0) {
+                    if (succHigh == 0) {
+                        int t = bits.decode(dcTab[c.td]);
+                        if (t < 0 || t > 15) return false;
+                        int diff = t ? JBits::extend(bits.get(t), t) : 0;
+                        c.dcPred += diff; dat[0] = (short)(c.dcPred * (1 << succLow));
+                    } else if (bits.get(1)) dat[0] = (short)(dat[0] + (short)(1 << succLow));
+                    return !bits.overrun;
+                }
+                if (succHigh == 0) {
+                    if (eobRun) { --eobRun; return true; }
+                    int k = specStart;
+                    do {
+                        int rs = bits.decode(acTab[c.ta]);
+                        if (rs < 0) return false;
+                        int sz = rs & 15, r = rs >> 4;
+                        if (sz == 0) {
+                            if (r < 15) { eobRun = 1 << r; if (r) eobRun += bits.get(r); --eobRun; break; }
+                            k += 16;
+                        } else { k += r; if (k > 63) return false; int zig = kDezigzag[k++]; dat[zig] = (short)(JBits::extend(bits.get(sz), sz) * (1 << succLow)); }
+                    } while (k <= specEnd);
+                } else {
+                    const short bit = (short)(1 << succLow);
+                    auto refine = [&](short& p) { if (bits.get(1) && (p & bit) == 0) p = (short)(p > 0 ? p + bit : p - bit); };
+                    if (eobRun) {
+                        --eobRun;
+                        for (int k = specStart; k <= specEnd; ++k) { short& p = dat[kDezigzag[k]]; if (p != 0) refine(p); }
+                    } else {
+                        int k = specStart;
+                        do {
+                            int rs = bits.decode(acTab[c.ta]);
+                            if (rs < 0) return false;
+                            int sz = rs & 15, r = rs >> 4; short nv = 0;
+                            if (sz == 0) {
+                                if (r < 15) { eobRun = (1 << r) - 1; if (r) eobRun += bits.get(r); r = 64; }   // r = 64: run to the end of the band
+                            } else { if (sz != 1) return false; nv = bits.get(1) ? bit : (short)-bit; }
+                            while (k <= specEnd) {
+                                short& p = dat[kDezigzag[k++]];
+                                if (p != 0) refine(p);
+                                else { if (r == 0) { p = nv; break; } --r; }
+                            }
+                        } while (k <= specEnd);
+                    }
+                }
+                return !bits.overrun;
+            };
             auto block = [&](JComp& c, int bx, int by) -> bool {
                 short coef[64]; std::memset(coef, 0, sizeof coef);
                 int t = bits.decode(dcTab[c.td]);
@@ -532,18 +759,19 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
                 if (--todo <= 0) {
                     if (bits.cnt < 24) bits.grow();
                     if (bits.marker < 0xD0 || bits.marker > 0xD7) return true;      // no restart marker here: the scan data ended (or is damaged); decode what is left as zeros
-                    bits.reset(); for (JComp& c : comps) c.dcPred = 0; todo = restart;
+                    bits.reset(); for (JComp& c : comps) c.dcPred = 0; eobRun = 0; todo = restart;
                 }
                 return true;
             };
             bool ok = true;
+            auto one_block = [&](JComp& c, int bx, int by) -> bool { return progressive ? block_prog(c, bx, by) : block(c, bx, by); };
             if (ns == 1) {
                 JComp& c = *scan[0]; int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
-                for (int j = 0; j < h && ok; ++j) for (int i = 0; i < w && ok; ++i) { ok = block(c, i, j) && after_mcu(); }
+                for (int j = 0; j < h && ok; ++j) for (int i = 0; i < w && ok; ++i) { ok = one_block(c, i, j) && after_mcu(); }
             } else {
                 int mcuX = (width + 8 * hmax - 1) / (8 * hmax), mcuY = (height + 8 * vmax - 1) / (8 * vmax);
                 for (int j = 0; j < mcuY && ok; ++j) for (int i = 0; i < mcuX && ok; ++i) {
-                    for (JComp* c : scan) for (int y = 0; y < c->v && ok; ++y) for (int x = 0; x < c->h && ok; ++x) ok = block(*c, i * c->h + x, j * c->v + y);
+                    for (JComp* c : scan) for (int y = 0; y < c->v && ok; ++y) for (int x = 0; x < c->h && ok; ++x) ok = one_block(*c, i * c->h + x, j * c->v + y);
                     ok = ok && after_mcu();
                 }
             }
@@ -558,6 +786,17 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
         pos += (size_t)len;
     }
     if (!sawSOF || !decoded) { err = "JPEG without image data"; return false; }
+    if (progressive) {      // all scans are in: dequantise and transform every block (stbi__jpeg_finish)
+        for (JComp& c : comps) {
+            if (!haveQuant[c.tq]) { err = "scan uses an undefined table"; return false; }
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+                short* dat = c.coeff.data() + 64 * ((size_t)i + (size_t)j * (size_t)(c.w2 >> 3));
+                for (int k = 0; k < 64; ++k) dat[k] = (short)(dat[k] * quant[c.tq][k]);
+                jidct_block(c.data.data() + (size_t)c.w2 * (size_t)j * 8 + (size_t)i * 8, (size_t)c.w2, dat);
+            }
+        }
+    }
     out.width = (uint32_t)width; out.height = (uint32_t)height; out.rgba.assign((size_t)width * height * 4, 255);
     const size_t nc = comps.size();
     std::vector<std::vector<uint8_t>> line(nc, std::vector<uint8_t>((size_t)width + 8 * 4 + 16));

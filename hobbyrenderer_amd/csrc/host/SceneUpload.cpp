@@ -15,7 +15,7 @@ int Scene::BuildAccelerationStructures(HrptContext* context)
     for (Texture& t : m_Textures) {
         if (t.m_BindlessIndex == UINT32_MAX) t.m_BindlessIndex = (uint32_t)table.size();
         if (table.size() <= t.m_BindlessIndex) table.resize((size_t)t.m_BindlessIndex + 1);
-        table[t.m_BindlessIndex] = { t.m_Pixels.data(), t.m_Width, t.m_Height };
+        table[t.m_BindlessIndex] = { t.m_Pixels.data(), t.m_Width, t.m_Height, t.m_Format, t.m_MipCount };
     }
     HrptSceneDesc d{};
     d.vertices = reinterpret_cast<const HrptVertexQuantized*>(m_Vertices.data()); d.vertexCount = (uint32_t)m_Vertices.size();

@@ -45,11 +45,11 @@ int hrsc_scene_load(const char* path, uint32_t flags, HrscScene** out)
     s->warnings = SceneLoader::Warnings();
     for (const std::string& w : s->warnings) if (w.rfind("mesh cache not used", 0) == 0) s->fromCache = false;
     // bindless table: default slots stay empty, scene textures sit at their bindless indices
-    s->textureTable.assign((size_t)srrhi::CommonConsts::DEFAULT_TEXTURE_COUNT, HrptTextureDesc{ nullptr, 0, 0 });
+    s->textureTable.assign((size_t)srrhi::CommonConsts::DEFAULT_TEXTURE_COUNT, HrptTextureDesc{ nullptr, 0, 0, 0, 0 });
     for (const hobbyrt::Scene::Texture& t : s->scene.m_Textures) {
         if (t.m_BindlessIndex == UINT32_MAX) continue;
-        if (s->textureTable.size() <= t.m_BindlessIndex) s->textureTable.resize((size_t)t.m_BindlessIndex + 1, HrptTextureDesc{ nullptr, 0, 0 });
-        s->textureTable[t.m_BindlessIndex] = HrptTextureDesc{ t.m_Pixels.data(), t.m_Width, t.m_Height };
+        if (s->textureTable.size() <= t.m_BindlessIndex) s->textureTable.resize((size_t)t.m_BindlessIndex + 1, HrptTextureDesc{ nullptr, 0, 0, 0, 0 });
+        s->textureTable[t.m_BindlessIndex] = HrptTextureDesc{ t.m_Pixels.data(), t.m_Width, t.m_Height, t.m_Format, t.m_MipCount };
     }
     *out = s;
     return HRSC_OK;
@@ -89,20 +89,32 @@ int hrsc_scene_view(const HrscScene* s, HrscSceneView* v)
 
 const char* hrsc_scene_warning(const HrscScene* s, uint32_t index) { return (s && index < s->warnings.size()) ? s->warnings[index].c_str() : nullptr; }
 
-int hrsc_decode_image(const uint8_t* bytes, size_t n, uint32_t* width, uint32_t* height, uint8_t** rgba)
+int hrsc_decode_image_ex(const uint8_t* bytes, size_t n, uint32_t* width, uint32_t* height, uint32_t* format, uint32_t* mipCount, uint8_t** texels, size_t* texelBytes)
 {
-    if (!bytes || !width || !height || !rgba) { SceneCache::SetLastError("hrsc_decode_image: null argument"); return HRSC_ERR_INVALID_ARG; }
+    if (!bytes || !width || !height || !format || !mipCount || !texels || !texelBytes) { SceneCache::SetLastError("hrsc_decode_image_ex: null argument"); return HRSC_ERR_INVALID_ARG; }
     hobbyrt::Image img; std::string err;
     bool decoded = false;
     try { decoded = hobbyrt::DecodeImage(bytes, n, img, err); } catch (const std::exception& e) { err = e.what(); }
     if (!decoded) { SceneCache::SetLastError("hrsc_decode_image: " + err); return HRSC_ERR_FORMAT; }
-    *rgba = static_cast<uint8_t*>(std::malloc(img.rgba.size() ? img.rgba.size() : 1));
-    if (!*rgba) { SceneCache::SetLastError("hrsc_decode_image: out of memory"); return HRSC_ERR_IO; }
-    std::memcpy(*rgba, img.rgba.data(), img.rgba.size());
-    *width = img.width; *height = img.height;
+    *texels = static_cast<uint8_t*>(std::malloc(img.rgba.size() ? img.rgba.size() : 1));
+    if (!*texels) { SceneCache::SetLastError("hrsc_decode_image: out of memory"); return HRSC_ERR_IO; }
+    std::memcpy(*texels, img.rgba.data(), img.rgba.size());
+    *width = img.width; *height = img.height; *format = img.format; *mipCount = img.mipCount; *texelBytes = img.rgba.size();
     return HRSC_OK;
 }
 
+int hrsc_decode_image(const uint8_t* bytes, size_t n, uint32_t* width, uint32_t* height, uint8_t** rgba)
+{
+    if (!bytes || !width || !height || !rgba) { SceneCache::SetLastError("hrsc_decode_image: null argument"); return HRSC_ERR_INVALID_ARG; }
+    uint32_t format = 0, mips = 0; size_t nb = 0;
+    int rc = hrsc_decode_image_ex(bytes, n, width, height, &format, &mips, rgba, &nb);
+    if (rc != HRSC_OK) return rc;
+    if (format > 1u) { std::free(*rgba); *rgba = nullptr; SceneCache::SetLastError("hrsc_decode_image: the file holds float texels; use hrsc_decode_image_ex"); return HRSC_ERR_FORMAT; }
+    return HRSC_OK;       // level 0 comes first: a caller that only knows width * height * 4 bytes reads exactly that level
+}
+
 void hrsc_free_pixels(uint8_t* rgba) { std::free(rgba); }
+
+int hrsc_selftest_bc7_tables(void) { return hobbyrt::Bc7TablesConsistent() ? HRSC_OK : HRSC_ERR_FORMAT; }
 
 } // extern "C"

@@ -311,13 +311,25 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
 
     std::vector<GpuTexture> table(s->textureCount);
     for (uint32_t i = 0; i < s->textureCount; ++i) {
-        table[i].rgba8 = nullptr; table[i].w = s->textures[i].width; table[i].h = s->textures[i].height;
-        if (s->textures[i].rgba8) {
-            if (s->textures[i].width == 0 || s->textures[i].height == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: zero-sized texture");
-            const uint8_t* d;
-            if ((r = upload(c, s->textures[i].rgba8, (size_t)s->textures[i].width * s->textures[i].height * 4, &d)) != HRPT_OK) return r;
-            table[i].rgba8 = d;
+        const HrptTextureDesc& td = s->textures[i];
+        GpuTexture& g = table[i];
+        memset(&g, 0, sizeof g);
+        g.w = td.width; g.h = td.height; g.format = td.format; g.mipCount = td.mipCount ? td.mipCount : 1u;
+        if (!td.texels) continue;
+        if (td.width == 0 || td.height == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: zero-sized texture");
+        if (td.format > HRPT_TEXTURE_FORMAT_RGBA32_FLOAT) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: unknown texture format");
+        if (g.mipCount > HRPT_TEXTURE_MAX_MIPS) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: more than HRPT_TEXTURE_MAX_MIPS mip levels");
+        uint64_t texels = 0;
+        for (uint32_t l = 0; l < g.mipCount; ++l) {
+            if (l > 0 && (td.width >> l) == 0 && (td.height >> l) == 0) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: more mip levels than the texture size allows");
+            g.mipOffset[l] = (uint32_t)texels;
+            texels += (uint64_t)((td.width >> l) ? (td.width >> l) : 1u) * ((td.height >> l) ? (td.height >> l) : 1u);
         }
+        if (texels > 0xFFFFFFFFull) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: texture too large");
+        const size_t bpt = td.format <= HRPT_TEXTURE_FORMAT_RGBA8_SRGB ? 4 : (td.format == HRPT_TEXTURE_FORMAT_RGBA16_FLOAT ? 8 : 16);
+        const uint8_t* d;
+        if ((r = upload(c, static_cast<const uint8_t*>(td.texels), (size_t)texels * bpt, &d)) != HRPT_OK) return r;
+        g.texels = d;
     }
     if ((r = upload(c, table.data(), table.size(), &v.textures)) != HRPT_OK) return r;
     v.textureCount = s->textureCount;

@@ -15,6 +15,7 @@
 
 #include "../../include/hobbyrt_pt.h"
 #include "../../include/hobbyrt/detmath.h"
+#include "../../include/hobbyrt/srgb_table.h"
 
 #define HRT_DEV __device__ __forceinline__
 
@@ -100,7 +101,10 @@ struct GpuTri {             // 48 B world-space triangle (instance transform app
 struct GpuTriAttr { float4 a, b, c, d, e; };   // a{n0,n1.x} b{n1.yz,n2.xy} c{n2.z,uv0,uv1.x} d{uv1.y,uv2,material} e{inst,prim,-,-}
 struct GpuTriTangent { float4 t0, t1, t2; };
 struct GpuInstShade { float4 adj0, adj1, adj2; };
-struct GpuTexture { const uint8_t* rgba8; uint32_t w, h; };
+struct GpuTexture {         // decoded texels of all levels (HrptTextureDesc); level l starts mipOffset[l] TEXELS after `texels`
+    const uint8_t* texels; uint32_t w, h, format, mipCount;
+    uint32_t mipOffset[HRPT_TEXTURE_MAX_MIPS];
+};
 
 struct SceneView {
     const GpuNode* nodes; uint32_t nodeCount;
@@ -426,41 +430,106 @@ HRT_DEV float unorm8_to_float(uint32_t byte)
     const float r = __builtin_fmaf(-q, 255.0f, x);
     return __builtin_fmaf(r, c, q);
 }
-HRT_DEV f4 texel8(const GpuTexture& t, int x, int y)
-{
-    uint32_t p = reinterpret_cast<const uint32_t*>(t.rgba8)[(size_t)y * t.w + (size_t)x];
-    f4 r;
-    r.x = unorm8_to_float(p & 255u); r.y = unorm8_to_float((p >> 8) & 255u);
-    r.z = unorm8_to_float((p >> 16) & 255u); r.w = unorm8_to_float(p >> 24);
-    return r;
-}
-// SampleBindlessTextureLevel(lod 0), Bindless.hlsli:118-123, on an RGBA8_UNORM single-mip texture with
-// exact fp32 bilinear weights. Sampler table src/CommonResources.cpp:117-128.
-HRT_DEV f4 sample_texture(const SceneView& s, uint32_t texIndex, uint32_t samplerIndex, f2 uv)
-{
-    f4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
-    if (texIndex >= s.textureCount) return zero;
-    GpuTexture t = s.textures[texIndex];
-    if (!t.rgba8) return zero;
-    bool wrap = (samplerIndex <= 5u) ? ((samplerIndex & 1u) != 0) : false;
-    bool point = (samplerIndex == 2u || samplerIndex == 3u);
-    float fx = uv.x * (float)t.w, fy = uv.y * (float)t.h;
-    if (point) return texel8(t, wrap_i((int)hrt_floor(fx), (int)t.w, wrap), wrap_i((int)hrt_floor(fy), (int)t.h, wrap));
-    fx = fx - 0.5f; fy = fy - 0.5f;
-    float ix = hrt_floor(fx), iy = hrt_floor(fy);
-    float tx = fx - ix, ty = fy - iy;
-    int x0 = wrap_i((int)ix, (int)t.w, wrap), x1 = wrap_i((int)ix + 1, (int)t.w, wrap);
-    int y0 = wrap_i((int)iy, (int)t.h, wrap), y1 = wrap_i((int)iy + 1, (int)t.h, wrap);
-    f4 a = lerp4(texel8(t, x0, y0), texel8(t, x1, y0), tx);
-    f4 b = lerp4(texel8(t, x0, y1), texel8(t, x1, y1), tx);
-    return lerp4(a, b, ty);
-}
 // binary16 -> binary32 is exact for every input, so the hardware conversion (v_cvt_f32_f16, fp16 denormals enabled --
 // the HIP default) gives the same bits as the integer decode of detmath.h (hrt_f16tof32) used on the host; checked for
 // all 65536 encodings by tests/test_parity_gpu.py::test_device_f16_decode_table.
 HRT_DEV float half_bits_to_float(uint32_t h)
 {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
+static __device__ __constant__ const float kSrgbToLinear[256] = HRT_SRGB_TO_LINEAR_TABLE;
+// One texel of a format other than RGBA8_UNORM: RGBA8_SRGB (r, g, b linearised BEFORE filtering, as a D3D12 sampler does for *_SRGB
+// formats), RGBA16_FLOAT, RGBA32_FLOAT.
+HRT_DEV f4 texel_fetch_other(const uint8_t* texels, uint32_t format, size_t idx)
+{
+    f4 r;
+    if (format == HRPT_TEXTURE_FORMAT_RGBA8_SRGB) {
+        const uint32_t p = reinterpret_cast<const uint32_t*>(texels)[idx];
+        r.x = kSrgbToLinear[p & 255u]; r.y = kSrgbToLinear[(p >> 8) & 255u]; r.z = kSrgbToLinear[(p >> 16) & 255u]; r.w = unorm8_to_float(p >> 24);
+    } else if (format == HRPT_TEXTURE_FORMAT_RGBA16_FLOAT) {
+        const uint2 p = reinterpret_cast<const uint2*>(texels)[idx];
+        r.x = half_bits_to_float(p.x & 0xffffu); r.y = half_bits_to_float(p.x >> 16); r.z = half_bits_to_float(p.y & 0xffffu); r.w = half_bits_to_float(p.y >> 16);
+    } else {
+        const float4 p = reinterpret_cast<const float4*>(texels)[idx];
+        r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+    }
+    return r;
+}
+HRT_DEV f4 texel_unorm8(const uint8_t* texels, size_t idx)
+{
+    const uint32_t p = reinterpret_cast<const uint32_t*>(texels)[idx];
+    f4 r;
+    r.x = unorm8_to_float(p & 255u); r.y = unorm8_to_float((p >> 8) & 255u); r.z = unorm8_to_float((p >> 16) & 255u); r.w = unorm8_to_float(p >> 24);
+    return r;
+}
+// One level of a texture sampled like SampleLevel on the samplers of src/CommonResources.cpp:117-128 (0/1 anisotropic, 2/3 point, 4/5
+// linear; odd = wrap, even = clamp), bilinear with exact fp32 weights: a(1 - t) + bt along x, then along y. levelOffset = first texel of
+// the level (0 for level 0). RGBA8_UNORM -- the format of every stb-decoded image, the hot path of textured scenes -- keeps its straight-
+// line code; the other formats share ONE copy of the fetch in a rolled loop over the four corners (inlined per corner and per texture slot
+// they doubled wf_shade's memory instructions and cost wf_shadow a wave of occupancy: +18 % / +30 % on the Sponza-class config).
+HRT_DEV f4 sample_texture_level(const uint8_t* texels, uint32_t format, int lw, int lh, uint32_t levelOffset, uint32_t samplerIndex, f2 uv)
+{
+    bool wrap = (samplerIndex <= 5u) ? ((samplerIndex & 1u) != 0) : false;
+    bool point = (samplerIndex == 2u || samplerIndex == 3u);
+    float fx = uv.x * (float)lw, fy = uv.y * (float)lh;
+    if (!point) { fx = fx - 0.5f; fy = fy - 0.5f; }
+    float ix = hrt_floor(fx), iy = hrt_floor(fy);
+    float tx = point ? 0.0f : fx - ix, ty = point ? 0.0f : fy - iy;
+    int x0 = wrap_i((int)ix, lw, wrap), x1 = wrap_i((int)ix + 1, lw, wrap);
+    int y0 = wrap_i((int)iy, lh, wrap), y1 = wrap_i((int)iy + 1, lh, wrap);
+    const size_t r0 = (size_t)levelOffset + (size_t)y0 * (size_t)lw, r1 = (size_t)levelOffset + (size_t)y1 * (size_t)lw;
+    if (format == HRPT_TEXTURE_FORMAT_RGBA8_UNORM) {
+        if (point) return texel_unorm8(texels, r0 + (size_t)x0);
+        f4 a = lerp4(texel_unorm8(texels, r0 + (size_t)x0), texel_unorm8(texels, r0 + (size_t)x1), tx);
+        f4 b = lerp4(texel_unorm8(texels, r1 + (size_t)x0), texel_unorm8(texels, r1 + (size_t)x1), tx);
+        return lerp4(a, b, ty);
+    }
+    if (point) return texel_fetch_other(texels, format, r0 + (size_t)x0);
+    f4 rowA, rowB; rowA.x = rowA.y = rowA.z = rowA.w = 0.0f; rowB = rowA;
+#pragma nounroll
+    for (uint32_t k = 0; k < 2u; ++k) {             // one copy of the two-texel row fetch
+        const size_t r = k ? r1 : r0;
+        const f4 v = lerp4(texel_fetch_other(texels, format, r + (size_t)x0), texel_fetch_other(texels, format, r + (size_t)x1), tx);
+        if (k == 0u) rowA = v; else rowB = v;
+    }
+    return lerp4(rowA, rowB, ty);
+}
+// SampleBindlessTextureLevel(lod 0), Bindless.hlsli:118-123.
+HRT_DEV f4 sample_texture(const SceneView& s, uint32_t texIndex, uint32_t samplerIndex, f2 uv)
+{
+    f4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
+    if (texIndex >= s.textureCount) return zero;
+    const GpuTexture& t = s.textures[texIndex];
+    const uint8_t* texels = t.texels;
+    if (!texels) return zero;
+    return sample_texture_level(texels, t.format, (int)t.w, (int)t.h, 0u, samplerIndex, uv);
+}
+// SampleBindlessTextureGrad, Bindless.hlsli:127-132 (tex.SampleGrad): D3D leaves the level-of-detail computation to the implementation
+// within a tolerance; defined here (numeric contract) as the isotropic form of the D3D11.3 functional spec 7.18.11:
+//   lod = log2(max(|ddx * size|, |ddy * size|)), clamped to [0, mipCount - 1]; linear / anisotropic samplers blend the two nearest levels
+//   with the fractional part (fp32), point samplers take the nearest level. A single-level texture is a level-0 sample.
+// The only caller passes ddx == ddy (GetShadowRayGradients, RaytracingCommon.hlsli:207-240), for which the anisotropic samplers'
+// footprint is isotropic as well.
+HRT_DEV f4 sample_texture_grad(const GpuTexture& t, uint32_t samplerIndex, f2 uv, f2 ddx, f2 ddy)
+{
+    const float ax = ddx.x * (float)t.w, ay = ddx.y * (float)t.h, bx = ddy.x * (float)t.w, by = ddy.y * (float)t.h;
+    const float rho2 = hrt_max(ax * ax + ay * ay, bx * bx + by * by);
+    float lod = rho2 > 0.0f ? 0.5f * hrt_log2(rho2) : 0.0f;
+    lod = hrt_clamp(lod, 0.0f, (float)(t.mipCount - 1u));
+    const bool point = (samplerIndex == 2u || samplerIndex == 3u);
+    const float l0 = point ? hrt_floor(lod + 0.5f) : hrt_floor(lod), f = point ? 0.0f : lod - l0;
+    const uint32_t i0 = (uint32_t)l0, i1 = i0 + 1u < t.mipCount ? i0 + 1u : i0;
+    f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+    // (a loop over the one or two levels, not two inlined copies of the bilinear fetch)
+    const uint32_t n = (f == 0.0f || i1 == i0) ? 1u : 2u;
+#pragma nounroll
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t lvl = k ? i1 : i0;
+        const int lw = (int)((t.w >> lvl) ? (t.w >> lvl) : 1u), lh = (int)((t.h >> lvl) ? (t.h >> lvl) : 1u);
+        const f4 v = sample_texture_level(t.texels, t.format, lw, lh, t.mipOffset[lvl], samplerIndex, uv);
+        if (k == 0) acc = v; else acc = lerp4(acc, v, f);
+    }
+    return acc;
 }
 HRT_DEV f4 lut_texel(const uint16_t* lut, size_t idx)
 {
@@ -776,6 +845,33 @@ HRT_DEV float candidate_alpha(const SceneView& s, const HrptMaterialConstants& m
     float alpha = mat.m_BaseColor[3];
     if (mat.m_TextureFlags & HRPT_TEXFLAG_ALBEDO) alpha *= sample_texture(s, mat.m_AlbedoTextureIndex, mat.m_AlbedoSamplerIndex, uv).w;
     return alpha;
+}
+
+// AlphaTestGrad's alpha (RaytracingCommon.hlsli:112-130) with the synthetic gradients of GetShadowRayGradients (:207-240): ddx = ddy =
+// uvRange * triangleArea / max(dist, 0.1), from the world-space triangle, the hit's barycentrics and the ray origin. Only textures with a
+// mip chain need them (a single-level texture is sampled at level 0 whatever the gradients are).
+HRT_DEV float candidate_alpha_grad(const SceneView& s, const HrptMaterialConstants& mat, f2 uv, const TriVerts& tv, uint32_t tri, float bu, float bv, f3 rayOrigin)
+{
+    float alpha = mat.m_BaseColor[3];
+    if (!(mat.m_TextureFlags & HRPT_TEXFLAG_ALBEDO)) return alpha;
+    const uint32_t ti = mat.m_AlbedoTextureIndex;
+    if (ti >= s.textureCount) return alpha * 0.0f;
+    const GpuTexture& t = s.textures[ti];
+    const uint8_t* texels = t.texels;
+    if (!texels) return alpha * 0.0f;
+    if (t.mipCount <= 1u) return alpha * sample_texture_level(texels, t.format, (int)t.w, (int)t.h, 0u, mat.m_AlbedoSamplerIndex, uv).w;
+    const GpuTri& g = s.tris[tri];
+    const f3 p0 = mk3(g.p0), p1 = mk3(g.p1), p2 = mk3(g.p2);
+    const float w0 = (1.0f - bu) - bv;
+    const f3 hitPos = (p0 * w0 + p1 * bu) + p2 * bv;
+    const float dist = length(hitPos - rayOrigin);
+    const float triangleArea = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+    f2 uvRange;
+    uvRange.x = hrt_max(tv.uv0.x, hrt_max(tv.uv1.x, tv.uv2.x)) - hrt_min(tv.uv0.x, hrt_min(tv.uv1.x, tv.uv2.x));
+    uvRange.y = hrt_max(tv.uv0.y, hrt_max(tv.uv1.y, tv.uv2.y)) - hrt_min(tv.uv0.y, hrt_min(tv.uv1.y, tv.uv2.y));
+    const float gradientScale = triangleArea / hrt_max(dist, 0.1f);
+    f2 grad; grad.x = uvRange.x * gradientScale; grad.y = uvRange.y * gradientScale;
+    return alpha * sample_texture_grad(t, mat.m_AlbedoSamplerIndex, uv, grad, grad).w;
 }
 
 struct SurfaceAttr { f3 worldPos, worldNormal, worldTangent; float tangentSign; f2 uv; };

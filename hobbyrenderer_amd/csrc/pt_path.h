@@ -90,8 +90,8 @@ HRT_DEV bool shadow_candidate(const SceneView& s, const Ray& ray, float hitT, ui
     const HrptMaterialConstants& mat = s.materials[tv.material];
     f2 uv = interpolated_uv(tv, bu, bv);
     if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
-        // AlphaTestGrad on single-mip textures == level-0 sample at the interpolated uv (RaytracingCommon.hlsli:112-130,207-240)
-        return candidate_alpha(s, mat, uv) >= mat.m_AlphaCutoff;
+        // AlphaTestGrad (RaytracingCommon.hlsli:112-130) with GetShadowRayGradients (:207-240); level 0 unless the texture has a mip chain
+        return candidate_alpha_grad(s, mat, uv, tv, tri, bu, bv, ray.o) >= mat.m_AlphaCutoff;
     }
     if (mat.m_AlphaMode != HRPT_ALPHA_MODE_BLEND) return true;
     float alpha = candidate_alpha(s, mat, uv);
@@ -129,14 +129,15 @@ HRT_DEV Ray shadow_ray(f3 worldPos, f3 L, float maxDist)                        
 }
 
 // Re-trace form: one closest-hit query per non-opaque candidate (validation megakernel).
-template <class BVH, class STACK>
+// ALL_OPAQUE: the scene is known (upload-time trait) to hold ForceOpaque instances only: the candidate pass is compiled out.
+template <bool ALL_OPAQUE = false, class BVH, class STACK>
 HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, uint32_t nodeLoopMin = 0)
 {
     Ray ray = shadow_ray(worldPos, L, maxDist);
     // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
     bool sawNonOpaque;
     if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque, nodeLoopMin)) return 0.0f;
-    if (!sawNonOpaque) return 1.0f;
+    if (ALL_OPAQUE || !sawNonOpaque) return 1.0f;
     ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
     HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
     for (;;) {   // non-opaque candidates, front to back

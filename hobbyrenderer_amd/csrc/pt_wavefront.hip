@@ -745,8 +745,10 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
 //   the recorded candidate lists (its stack serves the rare re-trace behind an overflowing list) and evaluates the contributions.
 // MODE kShadowSlim: kShadowOpaque with directional lights only and the 32-byte entries of wf_shade<1, SIMPLE> (see there).
 enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadowSlim = 3 };
+// (the buffered variant is held at 3 waves per SIMD: the gradient-sampled alpha test of mip-mapped MASK textures -- a rare path -- would
+// otherwise raise its register count past 170 and cost every scene with alpha-tested geometry a wave of occupancy)
 template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE>
-__global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;
     constexpr bool SLIM = MODE == kShadowSlim;
@@ -780,8 +782,8 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                     f3 L; float maxDist;
                     if (!nee_direction<true>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ux, uy, L, maxDist)) return;
                     float shadow;
-                    if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
-                    else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
+                    if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);
+                    else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
                     ++nRays;
                     if (shadow != 0.0f) {
                         const float4 th = a.b.thr[a.shadowParity][slot];
@@ -838,8 +840,8 @@ __global__ __launch_bounds__(kBlock) void wf_shadow(WfArgs a, HrptPathTracerCons
                         if (LDS_BVH) shadow = shadow_query_buffered<kShadowCandidates>(s, lbvh, origin, L, maxDist, stack, cand);
                         else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
                     } else {
-                        if (LDS_BVH) shadow = shadow_query(s, lbvh, origin, L, maxDist, stack);
-                        else shadow = shadow_query(s, gbvh, origin, L, maxDist, stack);
+                        if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);       // kShadowOpaque: no ForceNonOpaque instance in the scene
+                        else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
                     }
                     ++nRays;
                     if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped

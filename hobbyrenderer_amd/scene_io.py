@@ -102,7 +102,7 @@ def cache_is_valid(cache_path, source_path):
 
 # ---- glTF 2.0 ingestion (hrsc_scene_*) -------------------------------------------------------------------------------
 class _TextureDesc(C.Structure):
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("mipCount", C.c_uint32)]
 
 
 class _SceneView(C.Structure):
@@ -117,7 +117,9 @@ class _SceneView(C.Structure):
                 ("loadedFromMeshCache", C.c_uint32)]
 
 
-EXPORTS += ["hrsc_scene_load", "hrsc_scene_free", "hrsc_scene_view", "hrsc_scene_warning", "hrsc_decode_image", "hrsc_free_pixels"]
+EXPORTS += ["hrsc_scene_load", "hrsc_scene_free", "hrsc_scene_view", "hrsc_scene_warning", "hrsc_decode_image", "hrsc_decode_image_ex", "hrsc_free_pixels", "hrsc_selftest_bc7_tables"]
+lib.hrsc_decode_image_ex.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
 lib.hrsc_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
 lib.hrsc_scene_free.argtypes = [C.c_void_p]
 lib.hrsc_scene_free.restype = None
@@ -153,7 +155,13 @@ def load_gltf(path, luts, use_mesh_cache=False):
         textures = []
         for i in range(v.textureCount):
             t = v.textures[i]
-            textures.append(_copy(t.rgba8, t.width * t.height * 4, np.uint8).reshape(t.height, t.width, 4) if t.rgba8 else None)
+            if not t.texels:
+                textures.append(None)
+            elif t.format == 0 and t.mipCount <= 1:
+                textures.append(_copy(t.texels, t.width * t.height * 4, np.uint8).reshape(t.height, t.width, 4))
+            else:
+                nbytes = sum(w * h for w, h in S.mip_dims(t.width, t.height, t.mipCount)) * S.TEXTURE_BYTES_PER_TEXEL[t.format]
+                textures.append(S.Texture(_copy(t.texels, nbytes, np.uint8), t.width, t.height, t.format, t.mipCount))
         arrays = S.SceneArrays(_copy(v.vertices, v.vertexCount, S.VertexQuantized), _copy(v.indices, v.indexCount, np.uint32), _copy(v.meshData, v.meshDataCount, S.MeshData),
                                _copy(v.instances, v.instanceCount, S.PerInstanceData), _copy(v.materials, v.materialCount, S.MaterialConstants),
                                _copy(v.lights, v.lightCount, S.GPULight), luts, textures)
@@ -166,6 +174,18 @@ def load_gltf(path, luts, use_mesh_cache=False):
         return LoadedScene(arrays, camera, v.cameraCount, counts, warnings, bool(v.loadedFromMeshCache))
     finally:
         lib.hrsc_scene_free(h)
+
+
+def decode_texture(data):
+    """Image file bytes -> structs.Texture with the file's format and mip chain (hrsc_decode_image_ex)."""
+    w, h, f, m, p, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_void_p(), C.c_size_t()
+    rc = lib.hrsc_decode_image_ex(data, len(data), C.byref(w), C.byref(h), C.byref(f), C.byref(m), C.byref(p), C.byref(nb))
+    if rc != 0:
+        raise SceneFormatError(rc, lib.hrsc_last_error().decode())
+    try:
+        return S.Texture(_copy(p.value, nb.value, np.uint8), w.value, h.value, f.value, m.value)
+    finally:
+        lib.hrsc_free_pixels(p)
 
 
 def decode_image(data):

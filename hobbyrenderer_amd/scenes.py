@@ -128,7 +128,8 @@ class SceneBuilder:
         return len(self.materials) - 1
 
     def add_texture(self, rgba8):
-        self.textures.append(np.ascontiguousarray(rgba8, np.uint8))
+        """rgba8: (H, W, 4) uint8 array (RGBA8_UNORM, one level) or a structs.Texture (format + mip chain)."""
+        self.textures.append(rgba8 if isinstance(rgba8, S.Texture) else np.ascontiguousarray(rgba8, np.uint8))
         return len(self.textures) - 1
 
     def add_instance(self, mesh, material, world=None):

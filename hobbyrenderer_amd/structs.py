@@ -60,8 +60,38 @@ LUT_SCATTERING_SHAPE = (32, 128, 256, 4)
 LUT_IRRADIANCE_SHAPE = (16, 64, 4)
 
 
-class TextureDesc(C.Structure):
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+class TextureDesc(C.Structure):      # HrptTextureDesc
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("mipCount", C.c_uint32)]
+
+
+TEXTURE_FORMAT_RGBA8_UNORM, TEXTURE_FORMAT_RGBA8_SRGB, TEXTURE_FORMAT_RGBA16_FLOAT, TEXTURE_FORMAT_RGBA32_FLOAT = 0, 1, 2, 3
+TEXTURE_BYTES_PER_TEXEL = {0: 4, 1: 4, 2: 8, 3: 16}
+
+
+def mip_dims(width, height, mip_count):
+    return [(max(1, width >> l), max(1, height >> l)) for l in range(max(1, mip_count))]
+
+
+class Texture:
+    """A decoded texture with its format and mip chain (HrptTextureDesc): `data` = all levels, level 0 first, tightly packed bytes.
+    SceneArrays.textures entries are either one of these or a plain (H, W, 4) uint8 array (RGBA8_UNORM, one level)."""
+
+    def __init__(self, data, width, height, fmt=TEXTURE_FORMAT_RGBA8_UNORM, mip_count=1):
+        self.data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        self.width, self.height, self.format, self.mip_count = int(width), int(height), int(fmt), max(1, int(mip_count))
+        expect = sum(w * h for w, h in mip_dims(self.width, self.height, self.mip_count)) * TEXTURE_BYTES_PER_TEXEL[self.format]
+        if self.data.size != expect:
+            raise ValueError(f"texture data holds {self.data.size} bytes, {expect} expected for {width}x{height}, format {fmt}, {mip_count} level(s)")
+
+    def level(self, l):
+        """Level l as an array (h, w, 4) of uint8 / float16 / float32."""
+        dims = mip_dims(self.width, self.height, self.mip_count)
+        bpt = TEXTURE_BYTES_PER_TEXEL[self.format]
+        off = sum(w * h for w, h in dims[:l]) * bpt
+        w, h = dims[l]
+        raw = self.data[off:off + w * h * bpt]
+        dt = {4: np.uint8, 8: np.float16, 16: np.float32}[bpt]
+        return raw.view(dt).reshape(h, w, 4)
 
 
 class SceneDesc(C.Structure):
@@ -146,7 +176,7 @@ class SceneArrays:
         self.materials = np.ascontiguousarray(materials, MaterialConstants)
         self.lights = np.ascontiguousarray(lights, GPULight)
         self.lut_transmittance, self.lut_scattering, self.lut_irradiance = luts
-        self.textures = list(textures or [])   # list of None | uint8 array (h, w, 4)
+        self.textures = list(textures or [])   # list of None | uint8 array (h, w, 4) | Texture
         self.sun_direction = None              # filled by scene builders (Scene::GetSunDirection)
         self.sun_angular_size_deg = 0.533
 
@@ -168,10 +198,13 @@ class SceneArrays:
         if n:
             arr = (TextureDesc * n)()
             for i, t in enumerate(self.textures):
-                if t is not None:
+                if isinstance(t, Texture):
+                    keep.append(t.data)
+                    arr[i].texels, arr[i].height, arr[i].width, arr[i].format, arr[i].mipCount = t.data.ctypes.data, t.height, t.width, t.format, t.mip_count
+                elif t is not None:
                     t = np.ascontiguousarray(t, np.uint8)
                     keep.append(t)
-                    arr[i].rgba8, arr[i].height, arr[i].width = t.ctypes.data, t.shape[0], t.shape[1]
+                    arr[i].texels, arr[i].height, arr[i].width, arr[i].format, arr[i].mipCount = t.ctypes.data, t.shape[0], t.shape[1], 0, 1
             d.textures, d.textureCount = arr, n
             keep.append(arr)
         d.brunetonTransmittance = self.lut_transmittance.ctypes.data

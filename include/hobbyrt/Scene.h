@@ -49,7 +49,8 @@ public:
         int m_BaseColorTexture = -1, m_NormalTexture = -1, m_MetallicRoughnessTexture = -1, m_EmissiveTexture = -1;
     };
     struct Texture {
-        std::string m_Uri; std::vector<uint8_t> m_Pixels; uint32_t m_Width = 0, m_Height = 0;   // RGBA8_UNORM, one mip
+        std::string m_Uri; std::vector<uint8_t> m_Pixels; uint32_t m_Width = 0, m_Height = 0;   // decoded texels, all levels (HrptTextureDesc)
+        uint32_t m_Format = 0, m_MipCount = 1;   // HRPT_TEXTURE_FORMAT_* (stb images: RGBA8_UNORM, one level; DDS: the file's, src/TextureLoader.cpp:196-213)
         std::string m_SourceUri;            // the image's own URI when m_Uri was switched to a .dds sibling (fallback if that cannot be decoded)
         uint32_t m_BindlessIndex = UINT32_MAX;
         enum SamplerType { Clamp = 0, Wrap = 1 };

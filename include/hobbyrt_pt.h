@@ -168,11 +168,24 @@ enum {
     HRPT_LIGHT_DIRECTIONAL = 0, HRPT_LIGHT_POINT = 1, HRPT_LIGHT_SPOT = 2
 };
 
-/* A bindless 2D texture as the stb path of the reference produces it: RGBA8_UNORM,
- * one mip, no sRGB decode (src/TextureLoader.cpp:249-250). */
+/* A bindless 2D texture. The stb path of the reference produces RGBA8_UNORM with one level (src/TextureLoader.cpp:215-250); its DDS
+ * path keeps the file's format and mip chain (:66-135, :196-213): *_SRGB formats are linearised by the sampler BEFORE filtering,
+ * BC1-5 / BC7 decode to 8-bit channels, BC6H and the float formats to float channels. The caller hands over DECODED texels
+ * (hobbyrt::DecodeImage, include/hobbyrt_scene.h, does the block decompression): */
+enum {
+    HRPT_TEXTURE_FORMAT_RGBA8_UNORM = 0,   /* 4 bytes per texel */
+    HRPT_TEXTURE_FORMAT_RGBA8_SRGB = 1,    /* 4 bytes per texel; r, g, b through the sRGB -> linear table (include/hobbyrt/srgb_table.h), a linear */
+    HRPT_TEXTURE_FORMAT_RGBA16_FLOAT = 2,  /* 8 bytes per texel (binary16) */
+    HRPT_TEXTURE_FORMAT_RGBA32_FLOAT = 3   /* 16 bytes per texel */
+};
+#define HRPT_TEXTURE_MAX_MIPS 16
 typedef struct HrptTextureDesc {
-    const uint8_t* rgba8;                  /* width*height*4 bytes, row-major, may be NULL for an unused slot */
+    const void* texels;                    /* all levels, level 0 first, tightly packed, rows top to bottom; level l is max(1, width >> l) x
+                                              max(1, height >> l) texels; NULL for an unused slot */
     uint32_t width, height;
+    uint32_t format;                       /* HRPT_TEXTURE_FORMAT_* */
+    uint32_t mipCount;                     /* 0 or 1: level 0 only; at most HRPT_TEXTURE_MAX_MIPS. Only the gradient-sampled alpha test of shadow
+                                              rays (AlphaTestGrad, RaytracingCommon.hlsli:112-130,207-240) reads levels above 0 */
 } HrptTextureDesc;
 
 /* Everything the reference binds to PathTracerInputs (PathTracer.sr:19-32) plus the
@@ -186,7 +199,7 @@ typedef struct HrptSceneDesc {
     const HrptMaterialConstants* materials;  uint32_t materialCount;   /* MaterialConstantsFromMaterial output */
     const HrptGPULight*          lights;     uint32_t lightCount;      /* CreateAndUploadLightBuffer order */
     /* bindless Texture2D table, index = MaterialConstants::m_*TextureIndex. Slots 0..10 are the
-     * reference's default textures (Common.sr:103-113); entries with rgba8 == NULL are unbound. */
+     * reference's default textures (Common.sr:103-113); entries with texels == NULL are unbound. */
     const HrptTextureDesc*       textures;   uint32_t textureCount;
     /* Bruneton LUTs in the file format of bin/bruneton/{transmittance,scattering,irradiance}.dat: raw float32 RGBA. The library
      * converts to RGBA16F like CommonResources.cpp:550-558. irradiance may be NULL (not read on this path). */

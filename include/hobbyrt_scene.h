@@ -104,9 +104,15 @@ int  hrsc_scene_load(const char* path, uint32_t flags, HrscScene** out);
 void hrsc_scene_free(HrscScene* scene);
 int  hrsc_scene_view(const HrscScene* scene, HrscSceneView* out);          /* pointers stay valid until hrsc_scene_free */
 const char* hrsc_scene_warning(const HrscScene* scene, uint32_t index);   /* non-fatal findings of the load (skipped textures, ...) */
-/* PNG / DDS bytes -> RGBA8 (malloc'ed; release with hrsc_free_pixels). */
+/* PNG / JPEG / DDS bytes -> level 0 as RGBA8 (malloc'ed; release with hrsc_free_pixels); files with float texels are refused here. */
 int  hrsc_decode_image(const uint8_t* bytes, size_t byteCount, uint32_t* width, uint32_t* height, uint8_t** rgba);
+/* The same with everything the file holds: HRPT_TEXTURE_FORMAT_* of the decoded texels (DDS *_SRGB formats -> RGBA8_SRGB, BC6H and the
+ * float formats -> RGBA16_FLOAT / RGBA32_FLOAT) and all mip levels, level 0 first, tightly packed (src/TextureLoader.cpp:196-213). */
+int  hrsc_decode_image_ex(const uint8_t* bytes, size_t byteCount, uint32_t* width, uint32_t* height, uint32_t* format, uint32_t* mipCount,
+                          uint8_t** texels, size_t* texelBytes);
 void hrsc_free_pixels(uint8_t* rgba);
+/* 0 when the BC7 partition and anchor-index tables of the decoder agree with each other (every anchor lies in the subset it anchors). */
+int  hrsc_selftest_bc7_tables(void);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@
 #define _GNU_SOURCE
 #include "pt_oracle.h"
 #include "../include/hobbyrt/detmath.h"
+#include "../include/hobbyrt/srgb_table.h"
 
 #include <pthread.h>
 #include <stdio.h>
@@ -116,7 +117,7 @@ float or_half_to_float(uint16_t h) { return hrt_f16tof32(h); }
 /* ------------------------------------------------------------------ context */
 typedef struct { v3 p0, p1, p2; uint32_t inst, prim; uint32_t opaque; } WTri;
 typedef struct { float bmin[3], bmax[3]; int32_t left, right; uint32_t first, count; } BNode;
-typedef struct { uint8_t* rgba8; uint32_t w, h; } OTex;
+typedef struct { uint8_t* texels; uint32_t w, h, format, mipCount; uint32_t mipOffset[HRPT_TEXTURE_MAX_MIPS]; } OTex;   /* HrptTextureDesc: all levels, decoded texels */
 
 struct OrContext {
     HrptVertexQuantized* vertices; uint32_t vertexCount;
@@ -219,7 +220,7 @@ void or_destroy(OrContext* c)
 {
     if (!c) return;
     free(c->vertices); free(c->indices); free(c->meshData); free(c->instances); free(c->materials); free(c->lights);
-    if (c->textures) { for (uint32_t i = 0; i < c->textureCount; i++) free(c->textures[i].rgba8); free(c->textures); }
+    if (c->textures) { for (uint32_t i = 0; i < c->textureCount; i++) free(c->textures[i].texels); free(c->textures); }
     free(c->lutTransmittance); free(c->lutScattering); free(c->tris); free(c->triOrder); free(c->nodes);
     free(c);
 }
@@ -239,9 +240,18 @@ OrContext* or_create(const HrptSceneDesc* s)
     c->textureCount = s->textureCount;
     c->textures = (OTex*)calloc(s->textureCount ? s->textureCount : 1, sizeof(OTex));
     for (uint32_t i = 0; i < s->textureCount; i++) {
-        if (s->textures[i].rgba8) {
-            c->textures[i].w = s->textures[i].width; c->textures[i].h = s->textures[i].height;
-            c->textures[i].rgba8 = dup_mem(s->textures[i].rgba8, (size_t)s->textures[i].width * s->textures[i].height * 4);
+        if (s->textures[i].texels) {
+            OTex* t = &c->textures[i];
+            t->w = s->textures[i].width; t->h = s->textures[i].height; t->format = s->textures[i].format;
+            t->mipCount = s->textures[i].mipCount ? s->textures[i].mipCount : 1u;
+            if (t->w == 0 || t->h == 0 || t->format > HRPT_TEXTURE_FORMAT_RGBA32_FLOAT || t->mipCount > HRPT_TEXTURE_MAX_MIPS) { set_err("bad texture description"); or_destroy(c); return NULL; }
+            size_t texels = 0;
+            for (uint32_t l = 0; l < t->mipCount; l++) {
+                t->mipOffset[l] = (uint32_t)texels;
+                texels += (size_t)((t->w >> l) ? (t->w >> l) : 1u) * ((t->h >> l) ? (t->h >> l) : 1u);
+            }
+            size_t bpt = t->format <= HRPT_TEXTURE_FORMAT_RGBA8_SRGB ? 4 : (t->format == HRPT_TEXTURE_FORMAT_RGBA16_FLOAT ? 8 : 16);
+            t->texels = dup_mem(s->textures[i].texels, texels * bpt);
         }
     }
     /* LUTs: float32 file format -> RGBA16F, src/CommonResources.cpp:534-558 */
@@ -466,10 +476,24 @@ static int wrap_i(int i, int n, int wrap)
     if (wrap) { int m = i % n; return m < 0 ? m + n : m; }
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
-static v4 texel8(const OTex* t, int x, int y)
+static const float kSrgbToLinear[256] = HRT_SRGB_TO_LINEAR_TABLE;
+/* one texel of level `level` (lw texels wide), decoded per HRPT_TEXTURE_FORMAT_*; *_SRGB is linearised before filtering */
+static v4 texel_fetch(const OTex* t, uint32_t level, int lw, int x, int y)
 {
-    const uint8_t* p = t->rgba8 + ((size_t)y * t->w + (size_t)x) * 4;
-    v4 r = { (float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f };
+    size_t idx = (size_t)t->mipOffset[level] + (size_t)y * (size_t)lw + (size_t)x;
+    v4 r;
+    if (t->format <= HRPT_TEXTURE_FORMAT_RGBA8_SRGB) {
+        const uint8_t* p = t->texels + idx * 4;
+        if (t->format == HRPT_TEXTURE_FORMAT_RGBA8_SRGB) { r.x = kSrgbToLinear[p[0]]; r.y = kSrgbToLinear[p[1]]; r.z = kSrgbToLinear[p[2]]; }
+        else { r.x = (float)p[0] / 255.0f; r.y = (float)p[1] / 255.0f; r.z = (float)p[2] / 255.0f; }
+        r.w = (float)p[3] / 255.0f;
+    } else if (t->format == HRPT_TEXTURE_FORMAT_RGBA16_FLOAT) {
+        const uint16_t* p = (const uint16_t*)t->texels + idx * 4;
+        r.x = hrt_f16tof32(p[0]); r.y = hrt_f16tof32(p[1]); r.z = hrt_f16tof32(p[2]); r.w = hrt_f16tof32(p[3]);
+    } else {
+        const float* p = (const float*)t->texels + idx * 4;
+        r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+    }
     return r;
 }
 static v4 lerp4(v4 a, v4 b, float t)
@@ -477,26 +501,51 @@ static v4 lerp4(v4 a, v4 b, float t)
     v4 r = { a.x * (1.0f - t) + b.x * t, a.y * (1.0f - t) + b.y * t, a.z * (1.0f - t) + b.z * t, a.w * (1.0f - t) + b.w * t };
     return r;
 }
-static v4 sample_texture(const OrContext* c, uint32_t texIndex, uint32_t samplerIndex, v2 uv)
+static v4 sample_texture_level(const OTex* t, uint32_t samplerIndex, v2 uv, uint32_t level)
 {
-    v4 zero = { 0, 0, 0, 0 };
-    if (texIndex >= c->textureCount || !c->textures[texIndex].rgba8) return zero; /* unbound descriptor reads 0 */
-    const OTex* t = &c->textures[texIndex];
+    int lw = (int)((t->w >> level) ? (t->w >> level) : 1u), lh = (int)((t->h >> level) ? (t->h >> level) : 1u);
     int wrap = (samplerIndex <= 5u) ? (int)(samplerIndex & 1u) : 0;
     int point = (samplerIndex == 2u || samplerIndex == 3u);
-    float fx = uv.x * (float)t->w, fy = uv.y * (float)t->h;
+    float fx = uv.x * (float)lw, fy = uv.y * (float)lh;
     if (point) {
-        int x = wrap_i((int)hrt_floor(fx), (int)t->w, wrap), y = wrap_i((int)hrt_floor(fy), (int)t->h, wrap);
-        return texel8(t, x, y);
+        int x = wrap_i((int)hrt_floor(fx), lw, wrap), y = wrap_i((int)hrt_floor(fy), lh, wrap);
+        return texel_fetch(t, level, lw, x, y);
     }
     fx = fx - 0.5f; fy = fy - 0.5f;
     float ix = hrt_floor(fx), iy = hrt_floor(fy);
     float tx = fx - ix, ty = fy - iy;
-    int x0 = wrap_i((int)ix, (int)t->w, wrap), x1 = wrap_i((int)ix + 1, (int)t->w, wrap);
-    int y0 = wrap_i((int)iy, (int)t->h, wrap), y1 = wrap_i((int)iy + 1, (int)t->h, wrap);
-    v4 a = lerp4(texel8(t, x0, y0), texel8(t, x1, y0), tx);
-    v4 b = lerp4(texel8(t, x0, y1), texel8(t, x1, y1), tx);
+    int x0 = wrap_i((int)ix, lw, wrap), x1 = wrap_i((int)ix + 1, lw, wrap);
+    int y0 = wrap_i((int)iy, lh, wrap), y1 = wrap_i((int)iy + 1, lh, wrap);
+    v4 a = lerp4(texel_fetch(t, level, lw, x0, y0), texel_fetch(t, level, lw, x1, y0), tx);
+    v4 b = lerp4(texel_fetch(t, level, lw, x0, y1), texel_fetch(t, level, lw, x1, y1), tx);
     return lerp4(a, b, ty);
+}
+static v4 sample_texture(const OrContext* c, uint32_t texIndex, uint32_t samplerIndex, v2 uv)
+{
+    v4 zero = { 0, 0, 0, 0 };
+    if (texIndex >= c->textureCount || !c->textures[texIndex].texels) return zero; /* unbound descriptor reads 0 */
+    return sample_texture_level(&c->textures[texIndex], samplerIndex, uv, 0u);
+}
+/* tex.SampleGrad (Bindless.hlsli:127-132). Level of detail: the isotropic form of the D3D11.3 functional spec, fixed by the numeric
+ * contract (see pt_device.h sample_texture_grad): lod = log2(max(|ddx * size|, |ddy * size|)) clamped to the chain; linear and
+ * anisotropic samplers blend the two nearest levels, point samplers take the nearest. */
+static v4 sample_texture_grad(const OrContext* c, uint32_t texIndex, uint32_t samplerIndex, v2 uv, v2 ddx, v2 ddy)
+{
+    v4 zero = { 0, 0, 0, 0 };
+    if (texIndex >= c->textureCount || !c->textures[texIndex].texels) return zero;
+    const OTex* t = &c->textures[texIndex];
+    if (t->mipCount <= 1u) return sample_texture_level(t, samplerIndex, uv, 0u);
+    float ax = ddx.x * (float)t->w, ay = ddx.y * (float)t->h, bx = ddy.x * (float)t->w, by = ddy.y * (float)t->h;
+    float rho2 = hrt_max(ax * ax + ay * ay, bx * bx + by * by);
+    float lod = rho2 > 0.0f ? 0.5f * hrt_log2(rho2) : 0.0f;
+    lod = hrt_clamp(lod, 0.0f, (float)(t->mipCount - 1u));
+    int point = (samplerIndex == 2u || samplerIndex == 3u);
+    if (point) return sample_texture_level(t, samplerIndex, uv, (uint32_t)hrt_floor(lod + 0.5f));
+    float l0 = hrt_floor(lod), f = lod - l0;
+    uint32_t i0 = (uint32_t)l0, i1 = i0 + 1u < t->mipCount ? i0 + 1u : i0;
+    v4 a = sample_texture_level(t, samplerIndex, uv, i0);
+    if (f == 0.0f || i1 == i0) return a;
+    return lerp4(a, sample_texture_level(t, samplerIndex, uv, i1), f);
 }
 
 /* RGBA16F LUTs, linear-clamp sampler (index 4). */
@@ -897,10 +946,24 @@ static float calculate_rt_shadow(Tls* tl, v3 worldPos, v3 L, float maxDist)
         const HrptMeshData* mesh = &c->meshData[inst->m_MeshDataIndex];
         const HrptMaterialConstants* mat = &c->materials[inst->m_MaterialIndex];
         if (mat->m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
-            /* AlphaTestGrad with single-mip textures == lod-0 sample at grad.uv (RaytracingCommon.hlsli:207-240) */
+            /* AlphaTestGrad (RaytracingCommon.hlsli:112-130) with the gradients of GetShadowRayGradients (:207-240) */
             Vtx tv[3]; get_triangle_vertices(c, h.prim, inst->m_LODIndex, mesh, tv);
             v2 uv = interpolated_uv(tv, h.u, h.v);
-            if (candidate_alpha(c, mat, uv) >= mat->m_AlphaCutoff) { committed = 1; break; }
+            float alpha = mat->m_BaseColor[3];
+            if (mat->m_TextureFlags & HRPT_TEXFLAG_ALBEDO) {
+                v3 p0 = transform_point(tv[0].pos, inst->m_World), p1 = transform_point(tv[1].pos, inst->m_World), p2 = transform_point(tv[2].pos, inst->m_World);
+                float w0 = (1.0f - h.u) - h.v;
+                v3 hitPos = add3(add3(scale3(p0, w0), scale3(p1, h.u)), scale3(p2, h.v));
+                float dist = length3(sub3(hitPos, ray.o));
+                float triangleArea = length3(cross3(sub3(p1, p0), sub3(p2, p0))) * 0.5f;
+                v2 uvRange;
+                uvRange.x = hrt_max(tv[0].uv.x, hrt_max(tv[1].uv.x, tv[2].uv.x)) - hrt_min(tv[0].uv.x, hrt_min(tv[1].uv.x, tv[2].uv.x));
+                uvRange.y = hrt_max(tv[0].uv.y, hrt_max(tv[1].uv.y, tv[2].uv.y)) - hrt_min(tv[0].uv.y, hrt_min(tv[1].uv.y, tv[2].uv.y));
+                float gradientScale = triangleArea / hrt_max(dist, 0.1f);
+                v2 grad = { uvRange.x * gradientScale, uvRange.y * gradientScale };
+                alpha *= sample_texture_grad(c, mat->m_AlbedoTextureIndex, mat->m_AlbedoSamplerIndex, uv, grad, grad).w;
+            }
+            if (alpha >= mat->m_AlphaCutoff) { committed = 1; break; }
         } else if (mat->m_AlphaMode == HRPT_ALPHA_MODE_BLEND) {
             Vtx tv[3]; get_triangle_vertices(c, h.prim, inst->m_LODIndex, mesh, tv);
             v2 uv = interpolated_uv(tv, h.u, h.v);
