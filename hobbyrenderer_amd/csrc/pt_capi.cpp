@@ -678,19 +678,29 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
     if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: no scene uploaded");
     if (count == 0) return HRPT_OK;
     if (!rays || !hits) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: null array");
-    if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
+    if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS | HRPT_RAYS_THREAD_PER_RAY))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
     if (count > (1ull << 31)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: too many rays in one call");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool shadow = (flags & 0xFFu) == HRPT_RAYS_SHADOW;
+    // the persistent refilling traversal kernel (pt_wavefront.hip wf_trace_rays); the thread-per-ray kernel stays as the fallback for trees
+    // deeper than its stacks allow and as the cross-check (HRPT_RAYS_THREAD_PER_RAY)
+    const bool persistent = !(flags & HRPT_RAYS_THREAD_PER_RAY) && wavefront_trace_rays_supported(c->traits) && c->view.node4Count > 0;
+    auto trace = [&](const HrptRay* dr, HrptRayHit* dh) -> hipError_t {
+        if (!persistent) return launch_trace_rays(c->view, dr, dh, count, shadow, c->stream);
+        std::string werr;
+        hipError_t te = wavefront_trace_rays(c->wf, c->view, c->traits, dr, dh, count, shadow, c->stream, werr);
+        if (te != hipSuccess) c->err = "hrpt_trace_rays: " + werr;
+        return te;
+    };
     if (flags & HRPT_RAYS_DEVICE_POINTERS) {
-        HIP_TRY(c, launch_trace_rays(c->view, rays, hits, count, shadow, c->stream));
+        HIP_TRY(c, trace(rays, hits));
         return HRPT_OK;
     }
     HrptRay* dRays = nullptr; HrptRayHit* dHits = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&dRays), count * sizeof(HrptRay));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dHits), count * sizeof(HrptRayHit));
     if (e == hipSuccess) e = hipMemcpyAsync(dRays, rays, count * sizeof(HrptRay), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_trace_rays(c->view, dRays, dHits, count, shadow, c->stream);
+    if (e == hipSuccess) e = trace(dRays, dHits);
     if (e == hipSuccess) e = hipMemcpyAsync(hits, dHits, count * sizeof(HrptRayHit), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (dRays) (void)hipFree(dRays);

@@ -30,6 +30,8 @@ struct WavefrontState {
     size_t poolBytes = 0;
     void* spill = nullptr;             // traversal-stack overflow columns (only for trees deeper than the LDS stack)
     size_t spillBytes = 0;
+    void* traceSpill = nullptr;        // the same for hrpt_trace_rays batches
+    size_t traceSpillBytes = 0;
     // start/stop event pairs around every extend / shade / shadow launch; kind[i] = 0,1,2
     std::vector<hipEvent_t> events;
     std::vector<uint8_t> kind;
@@ -66,6 +68,10 @@ bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& c
 hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptPathTracerConstants& constants,
                             uint32_t accumCount, float4* accumulation, float4* output, uint32_t width, uint32_t height, TileRect rect,
                             DeviceCounters* counters, hipStream_t stream, std::string& error);
+// hrpt_trace_rays over device arrays through the persistent refilling traversal kernel (4-wide tree); false when the tree is too deep for it
+bool wavefront_trace_rays_supported(const SceneTraits& traits);
+hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptRay* rays, HrptRayHit* hits, uint64_t count,
+                                bool shadow, hipStream_t stream, std::string& error);
 void wavefront_release(WavefrontState& st);
 void wavefront_collect_timing(WavefrontState& st);   // call after the stream is synchronised; folds pending events into kernelMs
 void wavefront_reset_timing(WavefrontState& st);

@@ -421,6 +421,129 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     if (!ANYHIT) block_count_add(&a.counters->closestRays, 0, nRays);      // shadow rays are counted by wf_shadow
 }
 
+// ------------------------------------------------------------------ stand-alone ray queries (hrpt_trace_rays) through the same persistent loop
+// TraceRayStandard (RaytracingCommon.hlsli:138-198) / CalculateRTShadow<true> (CommonLighting.hlsli:380-496) for the reference's other inline-RT
+// passes (DDGI ProbeTraceCS.hlsl:60-61,108-109, RT shadows, BrdfRayTracing.hlsl:138-140): a caller's array of HrptRay instead of the path queue,
+// HrptRayHit records instead of hit records. A wave owns chunks of 256 consecutive rays and refills idle lanes exactly like wf_extend; the
+// thread-per-ray kernel of round 1 (pt_megakernel.hip) was 1.8x slower on the same rays. SHADOW: the any-hit traversal gathers the non-opaque
+// triangles a ray crosses in per-lane LDS columns; when the ray ends unblocked they are resolved front to back right there.
+struct WfTraceArgs {
+    SceneView scene; const HrptRay* rays; HrptRayHit* hits; uint64_t count;
+    int32_t* spill; uint32_t refillMin, nodeLoopMin;
+};
+constexpr uint32_t kTraceChunkShift = 8;
+template <bool LDS_BVH, int DEPTH, int W, bool SHADOW>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : 5))) void wf_trace_rays(WfTraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
+    constexpr size_t candBytes = SHADOW ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
+    LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kRows * kBlock * 4) + threadIdx.x;
+    if (DEPTH > kExtendLdsStack) { stack.spill = a.spill + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
+    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
+    const SceneView& s = a.scene;
+    const uint32_t wavesPerBlock = kBlock / 64;
+    const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
+    const uint64_t numChunks = (a.count + (1u << kTraceChunkShift) - 1) >> kTraceChunkShift;
+    const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
+
+    uint64_t chunk = gw; uint32_t cnt = 0, next = 0; uint64_t chunkBase = 0; bool haveChunk = false;
+    auto open_chunk = [&]() {
+        haveChunk = chunk < numChunks; next = 0;
+        if (haveChunk) { chunkBase = chunk << kTraceChunkShift; const uint64_t left = a.count - chunkBase; cnt = left < (1u << kTraceChunkShift) ? (uint32_t)left : (1u << kTraceChunkShift); }
+    };
+    open_chunk();
+    bool active = false;
+    Ray r; r.o = mk3(0.0f, 0.0f, 0.0f); r.d = mk3(0.0f, 0.0f, 1.0f); r.tmin = 0.0f; r.tmax = 1e10f;
+    RayShear sh = make_shear(r.d); f3 inv = mk3(0.0f, 0.0f, 0.0f), noi = mk3(0.0f, 0.0f, 0.0f);
+    HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
+    Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
+    int32_t cur = kTraversalDone; int sp = 0; uint64_t slot = 0; uint32_t rng = 0; float tlim = 0.0f;
+    bool blocked = false, candOverflow = false, finite = true; int candCount = 0;
+    for (;;) {
+        if (haveChunk && next >= cnt) { chunk += totalWaves; open_chunk(); }
+        const unsigned long long mIdle = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(mIdle);
+        if (haveChunk && (nIdle >= a.refillMin || nIdle == 64u)) {
+            const uint32_t idx = next + prefix_rank(mIdle);
+            if (!active && idx < cnt) {
+                slot = chunkBase + idx;
+                const float4* rp = reinterpret_cast<const float4*>(a.rays + slot);           // 48-byte records: three 16-byte loads
+                const float4 q0 = rp[0], q1 = rp[1]; const uint32_t rr = reinterpret_cast<const uint32_t*>(rp + 2)[0];
+                const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q1.x, q1.y, q1.z);
+                finite = d.x == d.x && d.y == d.y && d.z == d.z && o.x == o.x && o.y == o.y && o.z == o.z;
+                if (SHADOW) r = shadow_ray(o, d, q1.w);                                        // the query applies its own bias; tmax = distance to the light
+                else { r.o = o; r.d = d; r.tmin = q0.w; r.tmax = q1.w; }
+                rng = rr; blocked = false; candOverflow = false; candCount = 0; lower.have = false; best.valid = false; tlim = r.tmax; sp = 0;
+                sh = make_shear(r.d); inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv);
+                cur = (emptyScene || !finite) ? kTraversalDone : (s.nodeCount == 0 ? s.rootLeaf : 0);
+                active = true;
+            }
+            next += nIdle;
+        }
+        if (__ballot(active) == 0ull) { if (haveChunk) continue; break; }
+        if (active) {
+            while (cur >= 0) {
+                if (LDS_BVH) cur = inner_step(lbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+                else cur = inner_step(gbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
+                if ((uint32_t)__popcll(__ballot(cur >= 0)) < a.nodeLoopMin) break;
+            }
+            if (cur < 0 && cur != kTraversalDone) {
+                const uint32_t enc = (uint32_t)(~cur), first = enc >> 2, count = (enc & 3u) + 1u;
+                for (uint32_t i = 0; i < count; ++i) {
+                    float4 ta, tb, tc;
+                    if (LDS_BVH) lbvh.tri(first + i, ta, tb, tc); else gbvh.tri(first + i, ta, tb, tc);
+                    float t, u, v;
+                    if (tri_test(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), r, sh, t, u, v)) {
+                        if (SHADOW) {
+                            if (__float_as_uint(tc.w) & 1u) { blocked = true; break; }
+                            if (LDS_BVH) candidate_insert<kShadowCandidates>(lbvh, cand, candCount, candOverflow, t, first + i, __float_as_uint(ta.w), __float_as_uint(tb.w));
+                            else candidate_insert<kShadowCandidates>(gbvh, cand, candCount, candOverflow, t, first + i, __float_as_uint(ta.w), __float_as_uint(tb.w));
+                            continue;
+                        }
+                        const uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
+                        const bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+                        if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
+                            best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
+                            best.opaque = __float_as_uint(tc.w) & 1u; best.tri = first + i;
+                            tlim = t;
+                        }
+                    }
+                }
+                cur = (blocked || sp == 0) ? kTraversalDone : stack.pop(--sp);
+            }
+            if (cur == kTraversalDone) {
+                HrptRayHit out; out.t = 0.0f; out.u = 0.0f; out.v = 0.0f; out.instance = 0; out.primitive = 0; out.hit = 0; out.rng = rng; out.pad = 0;
+                bool done = true;
+                if (SHADOW) {
+                    float vis = 1.0f;
+                    if (finite) {
+                        if (blocked) vis = 0.0f;
+                        else if (candCount > 0) {
+                            if (LDS_BVH) vis = shadow_resolve_candidates(s, lbvh, r, sh, candCount, candOverflow, cand, stack);
+                            else vis = shadow_resolve_candidates(s, gbvh, r, sh, candCount, candOverflow, cand, stack);
+                        }
+                    }
+                    out.t = vis; out.hit = vis < 1.0f ? 1u : 0u;
+                } else if (best.valid && !best.opaque && !candidate_commits(s, best, rng)) {
+                    lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
+                    best.valid = false; tlim = r.tmax; sp = 0;
+                    cur = s.nodeCount == 0 ? s.rootLeaf : 0;
+                    done = false;
+                } else if (best.valid) { out.t = best.t; out.u = best.u; out.v = best.v; out.instance = best.inst; out.primitive = best.prim; out.hit = 1u; out.rng = rng; }
+                if (done) {
+                    out.rng = rng;
+                    float4* hp = reinterpret_cast<float4*>(a.hits + slot);
+                    hp[0] = make_float4(out.t, out.u, out.v, __uint_as_float(out.instance));
+                    hp[1] = make_float4(__uint_as_float(out.primitive), __uint_as_float(out.hit), __uint_as_float(out.rng), 0.0f);
+                    active = false;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ shade (+ compaction, + NEE sample emission)
 template <int MAXL>
 struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
@@ -976,6 +1099,57 @@ void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
 
 } // namespace
 
+namespace {
+template <bool L, int D, bool SH> void launch_trace_rays_t(dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
+{
+    hipLaunchKernelGGL((wf_trace_rays<L, D, 4, SH>), g, dim3(kBlock), lds + (SH ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0), st, a);
+}
+template <bool L, bool SH> void launch_trace_rays_d(int depth, dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
+{
+    if (depth <= 16) launch_trace_rays_t<L, 16, SH>(g, lds, st, a); else if (depth <= 32) launch_trace_rays_t<L, 32, SH>(g, lds, st, a); else launch_trace_rays_t<L, 64, SH>(g, lds, st, a);
+}
+}
+
+bool wavefront_trace_rays_supported(const SceneTraits& traits) { return 3 * traits.bvh4MaxDepth + 2 <= kMaxStackNeed; }
+
+hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptRay* rays, HrptRayHit* hits, uint64_t count,
+                                bool shadow, hipStream_t stream, std::string& error)
+{
+    if (count == 0) return hipSuccess;
+    hipError_t e; int dev = 0; hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    const uint32_t need = 3 * traits.bvh4MaxDepth + 2;
+    const int depth = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    const size_t candBytes = shadow ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
+    const size_t stackBytes = (size_t)(depth > kExtendLdsStack ? kExtendLdsStack : depth) * kBlock * 4;
+    const size_t bvhBytes = (size_t)scene.node4Count * 128 + (size_t)scene.triCount * 48;
+    const bool lds = bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
+    const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;
+    const uint64_t chunks = (count + 255) / 256, blocksNeeded = (chunks + 3) / 4;
+    uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = (uint32_t)blocksNeeded;
+    WfTraceArgs a{};
+    a.scene = scene; a.rays = rays; a.hits = hits; a.count = count;
+    a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
+    a.nodeLoopMin = st.nodeLoopMin != ~0u ? st.nodeLoopMin : (lds ? 16u : 24u);
+    if (depth > kExtendLdsStack) {
+        // own overflow columns (a render may be in flight on the context's buffers only in stream order, but sizes differ)
+        const uint32_t entries = need > (uint32_t)kExtendLdsStack ? need - kExtendLdsStack : 1u;
+        const size_t bytes = (size_t)cus * blocksPerCu * kBlock * entries * 4;
+        if (bytes > st.traceSpillBytes) {
+            if (st.traceSpill) { (void)hipStreamSynchronize(stream); (void)hipFree(st.traceSpill); st.traceSpill = nullptr; st.traceSpillBytes = 0; }
+            if ((e = hipMalloc(&st.traceSpill, bytes)) != hipSuccess) { error = "hipMalloc(traversal stack overflow)"; return e; }
+            st.traceSpillBytes = bytes;
+        }
+        a.spill = static_cast<int32_t*>(st.traceSpill);
+    }
+    const size_t ldsBytes = stackBytes + (lds ? bvhBytes : 0);
+    if (lds) { if (shadow) launch_trace_rays_d<true, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<true, false>(depth, dim3(grid), ldsBytes, stream, a); }
+    else { if (shadow) launch_trace_rays_d<false, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<false, false>(depth, dim3(grid), ldsBytes, stream, a); }
+    if ((e = hipGetLastError()) != hipSuccess) { error = "kernel launch"; return e; }
+    return hipSuccess;
+}
+
 bool wavefront_supports(const SceneView& scene, const HrptPathTracerConstants& cb)
 {
     (void)scene;
@@ -988,6 +1162,8 @@ void wavefront_release(WavefrontState& st)
     st.pool = nullptr; st.poolBytes = 0;
     if (st.spill) (void)hipFree(st.spill);
     st.spill = nullptr; st.spillBytes = 0;
+    if (st.traceSpill) (void)hipFree(st.traceSpill);
+    st.traceSpill = nullptr; st.traceSpillBytes = 0;
     for (hipEvent_t e : st.events) (void)hipEventDestroy(e);
     st.events.clear(); st.eventsUsed = 0;
     for (hipEvent_t e : st.forkEvents) (void)hipEventDestroy(e);

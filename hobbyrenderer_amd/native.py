@@ -185,11 +185,13 @@ class PathTracerContext:
         self._check(lib.hrpt_resolve_columns_device(self._h, C.c_void_p(int(shards_ptr)), C.c_void_p(int(accumulation_ptr or 0)) if accumulation_ptr else None,
                                                     C.c_void_p(int(output_ptr)), int(width), int(height), int(ranks), C.c_void_p(int(hip_stream))))
 
-    def trace_rays(self, rays, shadow=False):
-        """rays: structured array of S.Ray; returns a structured array of S.RayHit (see hrpt_trace_rays)."""
+    def trace_rays(self, rays, shadow=False, thread_per_ray=False):
+        """rays: structured array of S.Ray; returns a structured array of S.RayHit (see hrpt_trace_rays). thread_per_ray: the
+        one-thread-per-ray cross-check kernel instead of the persistent refilling traversal kernel."""
         rays = np.ascontiguousarray(rays, S.Ray)
         hits = np.zeros(len(rays), S.RayHit)
-        self._check(lib.hrpt_trace_rays(self._h, rays.ctypes.data, hits.ctypes.data, len(rays), S.RAYS_SHADOW if shadow else S.RAYS_CLOSEST))
+        flags = (S.RAYS_SHADOW if shadow else S.RAYS_CLOSEST) | (S.RAYS_THREAD_PER_RAY if thread_per_ray else 0)
+        self._check(lib.hrpt_trace_rays(self._h, rays.ctypes.data, hits.ctypes.data, len(rays), flags))
         return hits
 
     def set_shadow_overlap(self, enabled):

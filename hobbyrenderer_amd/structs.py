@@ -131,7 +131,7 @@ class Stats(C.Structure):
 
 Ray = np.dtype([("origin", f32, 3), ("tmin", f32), ("direction", f32, 3), ("tmax", f32), ("rng", u32), ("pad", u32, 3)])       # HrptRay, 48 B
 RayHit = np.dtype([("t", f32), ("u", f32), ("v", f32), ("instance", u32), ("primitive", u32), ("hit", u32), ("rng", u32), ("pad", u32)])   # HrptRayHit, 32 B
-RAYS_CLOSEST, RAYS_SHADOW, RAYS_DEVICE_POINTERS = 0, 1, 0x100
+RAYS_CLOSEST, RAYS_SHADOW, RAYS_DEVICE_POINTERS, RAYS_THREAD_PER_RAY = 0, 1, 0x100, 0x200
 
 
 class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B

@@ -367,6 +367,7 @@ typedef struct HrptRayHit { float t, u, v; uint32_t instance, primitive, hit, rn
 #define HRPT_RAYS_CLOSEST 0u
 #define HRPT_RAYS_SHADOW  1u
 #define HRPT_RAYS_DEVICE_POINTERS 0x100u
+#define HRPT_RAYS_THREAD_PER_RAY  0x200u   /* testing: the one-thread-per-ray kernel instead of the persistent refilling traversal kernel (same results) */
 int  hrpt_trace_rays(HrptContext* ctx, const HrptRay* rays, HrptRayHit* hits, uint64_t count, uint32_t flags);
 
 /* Host read-back (synchronises). bytes must be width*height*16. */

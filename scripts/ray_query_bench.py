@@ -15,7 +15,7 @@ for name, mk in (("config2", scenes.config_cornell), ("config4", scenes.config_s
     dr = torch.from_numpy(rays.view(np.uint8).reshape(n, 48)).cuda()
     dh = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    for kind, flag in (("closest", S.RAYS_CLOSEST), ("shadow", S.RAYS_SHADOW)):
+    for kind, flag in (("closest", S.RAYS_CLOSEST), ("shadow", S.RAYS_SHADOW), ("closest, thread per ray", S.RAYS_CLOSEST | S.RAYS_THREAD_PER_RAY), ("shadow, thread per ray", S.RAYS_SHADOW | S.RAYS_THREAD_PER_RAY)):
         ts = []
         for r in range(5):
             c.synchronize(); t0 = time.perf_counter()

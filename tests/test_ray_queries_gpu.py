@@ -62,6 +62,34 @@ def test_trace_rays_matches_oracle(luts, scene):
         o.close(); ctx.close()
 
 
+@pytest.mark.parametrize("scene", ["cornell", "soup", "glass", "sponza"])
+def test_persistent_and_thread_per_ray_kernels_agree(luts, scene):
+    """hrpt_trace_rays runs through the persistent refilling traversal kernel (wf_trace_rays: LDS-resident or global 4-wide tree, lane refill,
+    thresholded descent, per-lane candidate columns for the visibility query); the one-thread-per-ray kernel over the 2-wide tree is kept as
+    the cross-check. 300 k rays each, every record bit-identical -- including a ragged last chunk and the advanced RNG states."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    if scene == "cornell":
+        sc = scenes.config_cornell(luts, 64, 36, extra_lights=True)[0]
+    elif scene == "soup":
+        sc = random_soup(luts, 900, 33, 0.5, 0.3, True)
+    elif scene == "glass":
+        sc = scenes.config_glass(luts, 64, 36, detail=0.5)[0]
+    else:
+        sc = scenes.config_sponza_class(luts, 64, 36)[0]                      # ~100 k triangles: GPU-built tree in global memory, overflow stacks
+    rng = np.random.default_rng(17)
+    rays = _rays(rng, 300007, extent=3.0)
+    rays[5]["origin"] = (np.nan, 0, 0)
+    ctx = PathTracerContext(0)
+    try:
+        ctx.upload_scene(sc)
+        for shadow in (False, True):
+            a = ctx.trace_rays(rays, shadow=shadow)
+            b = ctx.trace_rays(rays, shadow=shadow, thread_per_ray=True)
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (scene, shadow, int((a.view(np.uint8).reshape(len(a), -1) != b.view(np.uint8).reshape(len(b), -1)).any(1).sum()))
+    finally:
+        ctx.close()
+
+
 def test_trace_rays_argument_checks(luts):
     from hobbyrenderer_amd.native import HrptError, PathTracerContext, lib
     ctx = PathTracerContext(0)
