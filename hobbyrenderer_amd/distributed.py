@@ -78,8 +78,8 @@ class PipelinedFrames:
 
     Lanes: `render_band` / `band_view` may be lists of L entries (one path-tracer context each) with `lane_streams` the L torch
     streams those contexts are bound to (hrpt_set_stream). Frame k is rendered by lane k % L, so L consecutive frames are in flight
-    on the GPU at once: a band is too little work to fill 256 CUs through the tail of every kernel (135 rows of config 2:
-    0.74 ms per frame with one lane, 0.62 ms with two, scripts/two_lane_band_probe.py). The gathers stay in frame order on the
+    on the GPU at once: a band is too little work to fill 256 CUs through the tail of every kernel (an eighth of config 2, round 2:
+    0.67 ms per frame with one lane, 0.52-0.55 with two, 0.48-0.51 with three, 0.47-0.50 with four, scripts/shard_host_overhead_probe.py). The gathers stay in frame order on the
     one comm stream (collectives must be issued in the same order on every rank).
 
     render_band(y0, y1): enqueues the band render on the lane's stream (the CURRENT torch stream when no lane_streams are given;
@@ -94,8 +94,8 @@ class PipelinedFrames:
         self.torch = torch
         self.render_band = list(render_band) if isinstance(render_band, (list, tuple)) else [render_band]
         self.band_view = list(band_view) if isinstance(band_view, (list, tuple)) else [band_view]
-        if len(self.render_band) != len(self.band_view) or not 1 <= len(self.render_band) <= 2:
-            raise ValueError("one or two lanes, each with a render_band and a band_view")
+        if len(self.render_band) != len(self.band_view) or not 1 <= len(self.render_band) <= 4:
+            raise ValueError("one to four lanes, each with a render_band and a band_view")
         self.lane_streams = list(lane_streams) if lane_streams is not None else None
         if self.lane_streams is not None and len(self.lane_streams) != len(self.render_band):
             raise ValueError("one stream per lane")
@@ -108,40 +108,43 @@ class PipelinedFrames:
             raise ValueError("layout is 'rows' (contiguous row bands) or 'columns' (interleaved 8-pixel columns)")
         self.layout = layout
         self.gpu = device.type == "cuda"
+        # staging / gathered / output slots: one per lane (at least two), frame k uses slot k % slots, so a frame's comm-stream work may still
+        # be running when the frames of the other lanes are submitted
+        self.slots = max(2, len(self.render_band))
         kw = dict(dtype=torch.float32, device=device)
         if layout == "rows":
             self.y0, self.y1 = band_for_rank(height, world, rank)
-            self.staging = [torch.empty((self.y1 - self.y0, width, 4), **kw) for _ in range(2)]
-            self.gathered = [torch.empty((height, width, 4), **kw) for _ in range(2)]
+            self.staging = [torch.empty((self.y1 - self.y0, width, 4), **kw) for _ in range(self.slots)]
+            self.gathered = [torch.empty((height, width, 4), **kw) for _ in range(self.slots)]
         else:
             # band_view is column_view(accumulation image of the lane, world, rank); render_band is called with the full row range
             if width % (8 * world) != 0:
                 raise ValueError(f"image width {width} must be a multiple of 8 * ranks = {8 * world}")
             self.y0, self.y1 = 0, height
-            self.staging = [torch.empty((height, width // 8 // world, 8, 4), **kw) for _ in range(2)]
-            self.shards = [torch.empty((world * height, width // 8 // world, 8, 4), **kw) for _ in range(2)]   # rank-major concatenation, as the collective delivers
-            self.gathered = [torch.empty((height, width, 4), **kw) for _ in range(2)]
-        self.output = [torch.empty((height, width, 4), **kw) for _ in range(2)]
+            self.staging = [torch.empty((height, width // 8 // world, 8, 4), **kw) for _ in range(self.slots)]
+            self.shards = [torch.empty((world * height, width // 8 // world, 8, 4), **kw) for _ in range(self.slots)]   # rank-major concatenation, as the collective delivers
+            self.gathered = [torch.empty((height, width, 4), **kw) for _ in range(self.slots)]
+        self.output = [torch.empty((height, width, 4), **kw) for _ in range(self.slots)]
         self.frame = 0
         if self.gpu:
             self.comm = torch.cuda.Stream(device)
-            self.rendered = [torch.cuda.Event() for _ in range(2)]
-            self.delivered = [torch.cuda.Event() for _ in range(2)]
+            self.rendered = [torch.cuda.Event() for _ in range(self.slots)]
+            self.delivered = [torch.cuda.Event() for _ in range(self.slots)]
             # device time of the comm-stream work (all-gather + re-assembly + resolve) of the frame in each slot
-            self.gather_begin = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            self.gather_end = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self.gather_begin = [torch.cuda.Event(enable_timing=True) for _ in range(self.slots)]
+            self.gather_end = [torch.cuda.Event(enable_timing=True) for _ in range(self.slots)]
 
     def submit(self):
         """Enqueue one frame; returns the slot (0/1) whose `gathered`/`output` images will hold it."""
         torch = self.torch
-        s = self.frame & 1
+        s = self.frame % self.slots
         lane = self.frame % len(self.render_band)
         if self.gpu:
             main = self.lane_streams[lane] if self.lane_streams is not None else torch.cuda.current_stream()
             with torch.cuda.stream(main):
-                if self.frame >= 2:
-                    main.wait_event(self.delivered[s])      # slot s is free again once frame-2's gather + resolve are done
                 self.render_band[lane](self.y0, self.y1)
+                if self.frame >= self.slots:
+                    main.wait_event(self.delivered[s])      # slot s is free again once the gather + resolve of the frame that used it are done
                 self.staging[s].copy_(self.band_view[lane])  # the only payload that crosses xGMI
                 self.rendered[s].record(main)
             with torch.cuda.stream(self.comm):
@@ -172,7 +175,7 @@ class PipelinedFrames:
         """Device time of the last submitted frame's comm-stream work (all-gather + resolve); call after the streams were synchronised."""
         if not self.gpu or self.frame == 0:
             return 0.0
-        s = (self.frame - 1) & 1
+        s = (self.frame - 1) % self.slots
         return float(self.gather_begin[s].elapsed_time(self.gather_end[s]))
 
     def finish(self):
