@@ -99,6 +99,9 @@ def main():
                          "(own streams, queues and images) so that one frame's kernel tails overlap the others'; 1 = one frame at a time; "
                          "0 = automatic: 2, or 3 when the image is sharded over several GPUs (a shard is too little work to fill the GPU through every "
                          "kernel's tail: one rank of eight, full pipeline: 0.56 ms per frame with 2 lanes, 0.51 with 3, 0.54 with 4)")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="evidence runs under rocprofv3 --kernel-trace: one frame in flight and no shadow / extend overlap inside a frame, so every launch "
+                         "runs alone and the tool's per-kernel averages are comparable with the HIP-event times of roofline.kernels (slower than the default)")
     ap.add_argument("--sharding", choices=("columns", "rows"), default="columns",
                     help="N>1: interleaved 8-pixel columns (every rank covers the whole picture: balanced) or contiguous row bands")
     ap.add_argument("--force-sharded", action="store_true", help="testing: run the N>1 code path (RCCL all-gather, comm stream) with a single rank")
@@ -154,6 +157,9 @@ def main():
     ctx.resize(W, H)
     lanes = [ctx]
     n_lanes = args.frames_in_flight if args.frames_in_flight else (3 if world >= 2 else 2)
+    if args.serial_kernels:
+        n_lanes = 1
+        ctx.set_shadow_overlap(False)
     if n_lanes > 1 and not rehearse:
         for _ in range(n_lanes - 1):
             c2 = native.PathTracerContext(local_rank)
@@ -320,7 +326,7 @@ def main():
             "config": {"workload": f"{workload}, {W}x{H}, {spp} spp (accumulation indices 0..{spp - 1}), {bounces} bounces",
                        "baseline_config": args.config, "baseline_parameters": (spp, bounces) == (base_spp, base_bounces) and (W, H) == (1920, 1080),
                        "sharding": (f"{world} rank(s), 8-pixel columns interleaved (column k on rank k mod {world}), BVH+scene replicated" if columns else f"{world} row band(s) of {rows} rows, BVH+scene replicated") + (", 1 RCCL all-gather of RGBA32F accumulation per step" + (" on a second stream, overlapped with the next step's render" if pipelined else "") if sharded else ""),
-                       "frames_in_flight": len(lanes),
+                       "frames_in_flight": len(lanes), "serial_kernels": bool(args.serial_kernels),
                        "mode": args.mode, "rays_per_step": total_rays / args.steps,
                        "closest_rays_per_step": closest_total / args.steps, "shadow_rays_per_step": shadow_total / args.steps},
         }
