@@ -29,6 +29,7 @@ struct Box {
 
 struct Builder {
     uint32_t minLeaf = 2;       // ranges this small always become a leaf
+    uint32_t maxLeaf = kMaxLeafTris;   // largest leaf the SAH termination may create (1 for the tree over instances)
     float triCost = 1.0f;       // SAH: cost of a triangle test relative to a node step
     std::vector<Prim> prims;
     const std::vector<HostTri>* src = nullptr;
@@ -78,7 +79,7 @@ struct Builder {
                 }
             }
         }
-        if (!forceMedian && count <= kMaxLeafTris && (bestAxis < 0 || bestCost >= leafCost)) return make_leaf(first, count);
+        if (!forceMedian && count <= maxLeaf && (bestAxis < 0 || bestCost >= leafCost)) return make_leaf(first, count);
 
         uint32_t mid;
         if (bestAxis >= 0 && !forceMedian) {
@@ -209,7 +210,7 @@ void collapse_bvh2_on_host(const std::vector<HostNode>& nodes2, std::vector<Host
     collapse4(nodes2, 0, nodes4, 0, maxDepth4);
 }
 
-bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& error)
+bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& error, bool flatLimit)
 {
     triCount = 0;
     if ((!s.vertices && s.vertexCount) || (!s.indices && s.indexCount) || (!s.meshData && s.meshDataCount) || (!s.instances && s.instanceCount) ||
@@ -226,7 +227,7 @@ bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& err
         if ((uint64_t)md.m_IndexOffsets[0] + md.m_IndexCounts[0] > s.indexCount || md.m_IndexCounts[0] % 3 != 0) { error = "mesh LOD0 index range invalid"; return false; }
         triCount += md.m_IndexCounts[0] / 3;
     }
-    if (triCount >= (1ull << 29)) { error = "too many triangles"; return false; }
+    if (flatLimit && triCount >= (1ull << 29)) { error = "too many triangles"; return false; }
     return true;
 }
 
@@ -321,6 +322,186 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
         }
     }
     return true;
+}
+
+// ---------------------------------------------------------------- two-level structure (instanced scenes)
+namespace {
+// inverse of the affine map p' = p * M (row-vector, translation in row 3), computed in binary64 and rounded once
+bool invert_affine(const float* M, float* inv12)
+{
+    const double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double r[9] = { (e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                          (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                          (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det };
+    const double t[3] = { M[12], M[13], M[14] };
+    for (int k = 0; k < 9; ++k) inv12[k] = (float)r[k];
+    for (int k = 0; k < 3; ++k) inv12[9 + k] = (float)-(t[0] * r[0 + k] + t[1] * r[3 + k] + t[2] * r[6 + k]);
+    for (int k = 0; k < 12; ++k) if (!std::isfinite(inv12[k])) return false;
+    return true;
+}
+
+// trees of the distinct meshes: one binned-SAH tree per MeshData entry that some instance uses
+bool build_mesh_trees(const HrptSceneDesc& s, BuiltTwoLevel& out, std::vector<int32_t>& meshRoot, std::string& error)
+{
+    meshRoot.assign(s.meshDataCount, 0);
+    std::vector<uint8_t> used(s.meshDataCount, 0);
+    for (uint32_t i = 0; i < s.instanceCount; ++i) used[s.instances[i].m_MeshDataIndex] = 1;
+    const bool needTangents = scene_needs_tangents(s);
+    for (uint32_t m = 0; m < s.meshDataCount; ++m) {
+        if (!used[m]) continue;
+        ++out.distinctMeshes;
+        const HrptMeshData& md = s.meshData[m];
+        const uint32_t nt = md.m_IndexCounts[0] / 3;
+        if (nt == 0) { meshRoot[m] = (int32_t)0x80000000; continue; }      // kTraversalDone: nothing to intersect
+        std::vector<HostTri> tris(nt);
+        for (uint32_t p = 0; p < nt; ++p) {
+            const uint32_t* ix = s.indices + md.m_IndexOffsets[0] + 3 * (size_t)p;
+            HostTri& t = tris[p];
+            for (int k = 0; k < 3; ++k) { t.p0[k] = s.vertices[ix[0]].m_Pos[k]; t.p1[k] = s.vertices[ix[1]].m_Pos[k]; t.p2[k] = s.vertices[ix[2]].m_Pos[k]; }
+            t.inst = m; t.prim = p; t.flags = 0;
+        }
+        BuiltBvh local;
+        Builder b; b.src = &tris; b.out = &local;
+        b.prims.resize(nt);
+        for (uint32_t p = 0; p < nt; ++p) {
+            Prim& pr = b.prims[p]; const HostTri& t = tris[p];
+            for (int k = 0; k < 3; ++k) {
+                float mn = std::min(t.p0[k], std::min(t.p1[k], t.p2[k])), mx = std::max(t.p0[k], std::max(t.p1[k], t.p2[k]));
+                if (!(mn == mn) || !(mx == mx) || std::isinf(mn) || std::isinf(mx)) { error = "non-finite vertex position"; return false; }
+                float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f;
+                pr.bmin[k] = mn - pad; pr.bmax[k] = mx + pad; pr.c[k] = 0.5f * mn + 0.5f * mx;
+            }
+            pr.tri = p;
+        }
+        Box root;
+        const int32_t r = b.build(0, nt, 0, root);
+        const uint32_t triBase = (uint32_t)out.tris.size(), nodeBase = (uint32_t)out.nodes4.size();
+        if ((uint64_t)triBase + nt >= (1ull << 29)) { error = "too many distinct triangles for the two-level structure"; return false; }
+        auto fix_leaf = [&](int32_t ref) { const uint32_t enc = (uint32_t)~ref; return ~(int32_t)((((enc >> 2) + triBase) << 2) | (enc & 3u)); };
+        if (r < 0) meshRoot[m] = fix_leaf(r);
+        else {
+            std::vector<HostNode4> n4; uint32_t d4 = 0;
+            collapse4(local.nodes, 0, n4, 0, d4);
+            out.maxDepth4Blas = std::max(out.maxDepth4Blas, d4 + 1);
+            for (HostNode4& n : n4) for (int k = 0; k < 4; ++k) {
+                if (n.child[k] == kEmptyChild) continue;
+                n.child[k] = n.child[k] >= 0 ? n.child[k] + (int32_t)nodeBase : fix_leaf(n.child[k]);
+            }
+            out.nodes4.insert(out.nodes4.end(), n4.begin(), n4.end());
+            meshRoot[m] = (int32_t)nodeBase;
+        }
+        // triangles + attributes of the mesh in leaf order
+        for (const HostTri& t : local.tris) {
+            out.tris.push_back(t);
+            const uint32_t* ix = s.indices + md.m_IndexOffsets[0] + 3 * (size_t)t.prim;
+            HostTriAttr a{};
+            unpack_normal(s.vertices[ix[0]], a.n0); unpack_normal(s.vertices[ix[1]], a.n1); unpack_normal(s.vertices[ix[2]], a.n2);
+            unpack_uv(s.vertices[ix[0]], a.uv0); unpack_uv(s.vertices[ix[1]], a.uv1); unpack_uv(s.vertices[ix[2]], a.uv2);
+            a.material = 0; a.inst = 0; a.prim = t.prim;
+            out.attrs.push_back(a);
+            if (needTangents) {
+                HostTriTangent tg;
+                unpack_tangent(s.vertices[ix[0]], tg.t0); unpack_tangent(s.vertices[ix[1]], tg.t1); unpack_tangent(s.vertices[ix[2]], tg.t2);
+                out.tangents.push_back(tg);
+            }
+        }
+    }
+    return true;
+}
+}
+
+bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error)
+{
+    // mesh roots are recovered from the existing instance records (same mesh -> same root)
+    std::vector<int32_t> meshRoot(s.meshDataCount, 0); std::vector<uint8_t> have(s.meshDataCount, 0);
+    for (const HostInstance& hi : out.instances) if (hi.mesh < s.meshDataCount) { meshRoot[hi.mesh] = hi.blasRoot; have[hi.mesh] = 1; }
+    for (uint32_t i = 0; i < s.instanceCount; ++i) if (!have[s.instances[i].m_MeshDataIndex]) { error = "instance uses a mesh without a tree"; return false; }
+    // object-space bounds per mesh from its triangles (leaf-order array; inst = mesh)
+    std::vector<Box> meshBox(s.meshDataCount);
+    for (const HostTri& t : out.tris) { meshBox[t.inst].grow(t.p0, t.p0); meshBox[t.inst].grow(t.p1, t.p1); meshBox[t.inst].grow(t.p2, t.p2); }
+    out.instances.assign(s.instanceCount, HostInstance{});
+    std::vector<HostTri> leafSrc(s.instanceCount);
+    Builder b; BuiltBvh tl; b.src = &leafSrc; b.out = &tl; b.minLeaf = 1; b.maxLeaf = 1;
+    b.prims.resize(s.instanceCount);
+    for (uint32_t i = 0; i < s.instanceCount; ++i) {
+        const HrptPerInstanceData& in = s.instances[i];
+        HostInstance& hi = out.instances[i];
+        const float* M = in.m_World;
+        for (int r = 0; r < 4; ++r) for (int k = 0; k < 3; ++k) hi.world[3 * r + k] = M[4 * r + k];
+        if (!invert_affine(M, hi.inv)) { error = "instance " + std::to_string(i) + " has a singular world matrix: the two-level structure cannot represent it"; return false; }
+        hi.blasRoot = meshRoot[in.m_MeshDataIndex]; hi.flags = triangle_flags_for_material(s.materials[in.m_MaterialIndex]); hi.material = in.m_MaterialIndex;
+        hi.mesh = in.m_MeshDataIndex;
+        // world box: the eight corners of the mesh's object box through the flat path's transform, padded like every box
+        const Box& ob = meshBox[in.m_MeshDataIndex];
+        Box wb; float maxAbs = 0.0f;
+        if (ob.mn[0] <= ob.mx[0]) {
+            for (int c = 0; c < 8; ++c) {
+                const float p[3] = { (c & 1) ? ob.mx[0] : ob.mn[0], (c & 2) ? ob.mx[1] : ob.mn[1], (c & 4) ? ob.mx[2] : ob.mn[2] };
+                float w[3]; transform_point(p, M, w);
+                for (int k = 0; k < 3; ++k) if (!std::isfinite(w[k])) { error = "non-finite vertex position"; return false; }
+                wb.grow(w, w);
+            }
+            for (int k = 0; k < 3; ++k) {
+                maxAbs = std::max(maxAbs, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])));
+                const float pad = 1e-5f * std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + 1e-6f;
+                wb.mn[k] -= pad; wb.mx[k] += pad;
+            }
+        } else { for (int k = 0; k < 3; ++k) { wb.mn[k] = wb.mx[k] = M[12 + k]; } }
+        // a world-space vertex is rounded to binary32 after the transform; the error is mapped back to object space through |Minv| and taken
+        // eight times over
+        float invNorm = 0.0f;
+        for (int k = 0; k < 3; ++k) invNorm = std::max(invNorm, std::fabs(hi.inv[k]) + std::fabs(hi.inv[3 + k]) + std::fabs(hi.inv[6 + k]));
+        hi.invNorm = invNorm;
+        float om = 0.0f;
+        if (ob.mn[0] <= ob.mx[0]) for (int k = 0; k < 3; ++k) om = std::max(om, std::max(std::fabs(ob.mn[k]), std::fabs(ob.mx[k])));
+        hi.objMaxAbs = om * (1.0f + 1e-5f) + 1e-6f;
+        // every partial sum of transform_point is bounded by |p|max * (column sum of |M|) + |T|: three roundings of at most half an ulp of that
+        float fwdNorm = 0.0f, tMax = 0.0f;
+        for (int k = 0; k < 3; ++k) { fwdNorm = std::max(fwdNorm, std::fabs(M[k]) + std::fabs(M[4 + k]) + std::fabs(M[8 + k])); tMax = std::max(tMax, std::fabs(M[12 + k])); }
+        hi.boxEps = 8.0f * 2.4e-7f * std::max(maxAbs, om * fwdNorm + tMax) * invNorm;
+        Prim& pr = b.prims[i];
+        for (int k = 0; k < 3; ++k) { pr.bmin[k] = wb.mn[k]; pr.bmax[k] = wb.mx[k]; pr.c[k] = 0.5f * wb.mn[k] + 0.5f * wb.mx[k]; }
+        pr.tri = i; leafSrc[i].inst = i; leafSrc[i].prim = 0; leafSrc[i].flags = 0;
+    }
+    build_instance_shade(s, out.instShade);
+    // the tree over the instances replaces the first tlasNodeCount nodes: rebuild the array with the mesh trees shifted if its size changes
+    std::vector<HostNode4> tlas; uint32_t dT = 0; int32_t rootLeaf = 0;
+    if (s.instanceCount > 0) {
+        Box root;
+        const int32_t r = b.build(0, s.instanceCount, 0, root);
+        auto inst_leaf = [&](int32_t ref) { const uint32_t first = ((uint32_t)~ref) >> 2; return ~(int32_t)(tl.tris[first].inst << 2); };
+        if (r < 0) rootLeaf = inst_leaf(r);
+        else {
+            collapse4(tl.nodes, 0, tlas, 0, dT); dT += 1;
+            for (HostNode4& n : tlas) for (int k = 0; k < 4; ++k) if (n.child[k] != kEmptyChild && n.child[k] < 0) n.child[k] = inst_leaf(n.child[k]);
+        }
+    }
+    const int32_t shift = (int32_t)tlas.size() - (int32_t)out.tlasNodeCount;
+    std::vector<HostNode4> all; all.reserve(out.nodes4.size() + (size_t)std::max(shift, 0));
+    all.insert(all.end(), tlas.begin(), tlas.end());
+    all.insert(all.end(), out.nodes4.begin() + out.tlasNodeCount, out.nodes4.end());
+    if (shift != 0) {
+        for (size_t k = tlas.size(); k < all.size(); ++k) for (int c = 0; c < 4; ++c) if (all[k].child[c] != kEmptyChild && all[k].child[c] >= 0) all[k].child[c] += shift;
+        for (HostInstance& hi : out.instances) if (hi.blasRoot >= 0) hi.blasRoot += shift;
+    }
+    out.nodes4.swap(all); out.tlasNodeCount = (uint32_t)tlas.size(); out.tlasRootLeaf = rootLeaf; out.maxDepth4Tlas = dT;
+    return true;
+}
+
+bool build_scene_two_level(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error)
+{
+    out = BuiltTwoLevel();
+    uint64_t triCount = 0;
+    if (!validate_scene(s, triCount, error, false)) return false;
+    if (s.instanceCount >= (1u << 29)) { error = "too many instances for the two-level structure"; return false; }
+    std::vector<int32_t> meshRoot;
+    if (!build_mesh_trees(s, out, meshRoot, error)) return false;
+    // seed instance records so that rebuild_two_level_instances finds the mesh roots
+    out.instances.assign(s.instanceCount, HostInstance{});
+    for (uint32_t i = 0; i < s.instanceCount; ++i) { out.instances[i].mesh = s.instances[i].m_MeshDataIndex; out.instances[i].blasRoot = meshRoot[s.instances[i].m_MeshDataIndex]; }
+    return rebuild_two_level_instances(s, out, error);
 }
 
 } // namespace hrt

@@ -82,12 +82,53 @@ struct BuiltBvh {
     float sahCost = 0.0f;           // SAH cost of the 2-wide tree (node cost 1, triangle cost 1), root area = 1
 };
 
+// ---- two-level structure for instanced scenes (the reference's own form: one BLAS per mesh + a TLAS of instances, src/Scene.cpp:98-154) ----
+// The flat tree above costs memory and build time proportional to instances x triangles. For scenes where that product is large the
+// library keeps one object-space tree per DISTINCT mesh and a tree over the instances' world boxes instead. The hit definition does not
+// change: at a leaf the traversal transforms the three object-space vertices with the instance's m_World exactly as the flat upload
+// does (transform_point) and runs the same watertight test on the world-space ray, so (t, u, v) and the (t, instance, primitive) order
+// are bit-identical to the flat path; only the culling runs on an object-space ray.
+struct HostInstance {           // mirrors hrt::GpuInstance (pt_device.h), 128 B
+    float world[12];            // rows 0..3 of m_World, xyz each (row-vector convention: p_world = p * M, translation in row 3)
+    float inv[12];              // the inverse map in the same layout: p_object = p_world * Minv
+    int32_t blasRoot;           // node4 index of the mesh's tree (>= 0) or an encoded leaf (< 0) when the whole mesh is one leaf
+    uint32_t flags;             // triangle_flags_for_material of the instance's material (bit 0 opaque, bits 1-2 shading class)
+    uint32_t material;
+    float boxEps;               // object-space slack added to both sides of every BLAS slab: the fp32 rounding of the world-space vertices
+                                // (half an ulp of the instance's largest world coordinate) mapped back through |Minv|, times a safety factor
+    uint32_t mesh;
+    float objMaxAbs;            // largest |coordinate| of the mesh's (padded) object-space box
+    float invNorm;              // max column sum of |Minv| (bounds |v * Minv| by invNorm * max|v_k|)
+    uint32_t pad;
+};
+static_assert(sizeof(HostInstance) == 128, "GPU layouts");
+struct BuiltTwoLevel {
+    std::vector<HostNode4> nodes4;        // [0, tlasNodeCount): the tree over instances (root 0, leaves = one instance: ~((instance << 2) | 0));
+                                          // behind it the trees of the distinct meshes, child indices already offset into this array
+    uint32_t tlasNodeCount = 0;
+    int32_t tlasRootLeaf = 0;             // encoded instance leaf when the scene has a single instance (no TLAS nodes)
+    std::vector<HostTri> tris;            // object-space triangles of all distinct meshes in leaf order (inst = mesh index, prim = primitive, flags = 0)
+    std::vector<HostTriAttr> attrs;       // parallel to tris (material / inst fields unused: they come from the instance)
+    std::vector<HostTriTangent> tangents;
+    std::vector<HostInstance> instances;
+    std::vector<HostInstShade> instShade;
+    uint32_t maxDepth4Tlas = 0, maxDepth4Blas = 0;
+    uint32_t distinctMeshes = 0;
+};
+// Stack need of the two-level traversal: 3 entries per 4-wide level of both trees + the BLAS exit marker + 2.
+inline uint32_t two_level_stack_need(const BuiltTwoLevel& b) { return 3u * (b.maxDepth4Tlas + b.maxDepth4Blas) + 3u; }
+bool build_scene_two_level(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error);
+// The instance records + the tree over the instances only (moving objects: the per-frame TLAS rebuild of src/CommonRenderers.cpp:234-246);
+// `out` keeps its mesh trees.
+bool rebuild_two_level_instances(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error);
+
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr uint32_t kTraversalStackDepth = 64;   // 2-wide trees: the builders guarantee depth + 2 <= this (private / LDS + overflow stacks of the kernels)
 constexpr uint32_t kHostBuilderDepthGoal = 32;  // the host SAH builder switches to median splits early enough to stay below this
 
 // Validates every index / range of the scene description (false + message); triCount = world triangles over all instances.
-bool validate_scene(const HrptSceneDesc& scene, uint64_t& triCount, std::string& error);
+// (flatLimit: the flat tree's leaf references hold triangle indices below 2^29; the two-level structure only limits DISTINCT triangles)
+bool validate_scene(const HrptSceneDesc& scene, uint64_t& triCount, std::string& error, bool flatLimit = true);
 void build_instance_shade(const HrptSceneDesc& scene, std::vector<HostInstShade>& out);
 bool scene_needs_tangents(const HrptSceneDesc& scene);
 // validate_scene + host build (binned SAH).

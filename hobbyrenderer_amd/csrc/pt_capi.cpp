@@ -48,6 +48,9 @@ struct HrptContext {
     WavefrontState wf;
     SceneTraits traits;
     int bvhBuilder = HRPT_BVH_BUILDER_AUTO;       // hrpt_set_bvh_builder
+    int accelStructure = HRPT_ACCEL_AUTO;         // hrpt_set_acceleration_structure
+    BuiltTwoLevel* twoLevel = nullptr;            // two-level scenes: host copy (hrpt_update_instances rebuilds the instance tree from it)
+    std::vector<void*> meshAllocations;           // ... and the device copies of the per-mesh arrays, which survive instance updates
     uint32_t megakernelFallbacks = 0;             // renders that wanted the wavefront pipeline but could not use it (HrptStats)
     HrptBuildInfo buildInfo{};
 };
@@ -91,7 +94,12 @@ static void free_acceleration(HrptContext* c, bool keepGpuBuilder)
 {
     for (void* p : c->bvhAllocations) (void)hipFree(p);
     c->bvhAllocations.clear();
-    if (!keepGpuBuilder) { delete c->gpuBuilder; c->gpuBuilder = nullptr; }
+    if (!keepGpuBuilder) {
+        delete c->gpuBuilder; c->gpuBuilder = nullptr;
+        for (void* p : c->meshAllocations) (void)hipFree(p);
+        c->meshAllocations.clear();
+        delete c->twoLevel; c->twoLevel = nullptr;
+    }
 }
 
 static void free_scene(HrptContext* c)
@@ -186,6 +194,59 @@ const char* hrpt_last_error(const HrptContext* c)
 // The acceleration structure + the records derived from instance transforms (Scene::BuildAccelerationStructures, src/Scene.cpp:67-214),
 // written into `v`. First build of a scene or a rebuild after hrpt_update_instances (the GPU builder then keeps its device-resident
 // geometry and buffers).
+// Two-level structure: qualifies when every instance is ForceOpaque (src/Scene.cpp:150-154: material alpha mode OPAQUE)
+static bool two_level_wanted(const HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris)
+{
+    int want = c->accelStructure;
+    if (const char* e = getenv("HRPT_ACCEL_STRUCTURE")) { const int v = atoi(e); if (v >= HRPT_ACCEL_AUTO && v <= HRPT_ACCEL_TWO_LEVEL) want = v; }
+    if (want == HRPT_ACCEL_FLAT || s.instanceCount == 0) return false;
+    for (uint32_t i = 0; i < s.instanceCount; ++i)
+        if (s.materials[s.instances[i].m_MaterialIndex].m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) return false;
+    if (want == HRPT_ACCEL_TWO_LEVEL) return true;
+    std::vector<uint8_t> used(s.meshDataCount, 0); uint32_t distinct = 0;
+    for (uint32_t i = 0; i < s.instanceCount; ++i) if (!used[s.instances[i].m_MeshDataIndex]) { used[s.instances[i].m_MeshDataIndex] = 1; ++distinct; }
+    return sceneTris >= (2ull << 20) && (uint64_t)s.instanceCount >= 8ull * distinct;
+}
+
+// instancesOnly: the mesh trees of c->twoLevel are kept (hrpt_update_instances)
+static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v, bool instancesOnly)
+{
+    std::string berr; int r;
+    if (!instancesOnly) {
+        delete c->twoLevel; c->twoLevel = new BuiltTwoLevel();
+        if (!build_scene_two_level(s, *c->twoLevel, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+    } else if (!rebuild_two_level_instances(s, *c->twoLevel, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+    const BuiltTwoLevel& b = *c->twoLevel;
+    if (two_level_stack_need(b) > 128u) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: two-level trees too deep for the traversal stacks");
+    if (!instancesOnly) {
+        const HostTri* dt; const HostTriAttr* da; const HostTriTangent* dtg;
+        if ((r = upload(c, b.tris.data(), b.tris.size(), &dt, &c->meshAllocations)) != HRPT_OK) return r;
+        if ((r = upload(c, b.attrs.data(), b.attrs.size(), &da, &c->meshAllocations)) != HRPT_OK) return r;
+        v.tris = reinterpret_cast<const GpuTri*>(dt); v.triCount = (uint32_t)b.tris.size(); v.attrs = reinterpret_cast<const GpuTriAttr*>(da);
+        v.tangents = nullptr;
+        if (!b.tangents.empty()) {
+            if ((r = upload(c, b.tangents.data(), b.tangents.size(), &dtg, &c->meshAllocations)) != HRPT_OK) return r;
+            v.tangents = reinterpret_cast<const GpuTriTangent*>(dtg);
+        }
+    }
+    const HostNode4* dn4; const HostInstance* di; const HostInstShade* dis;
+    if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
+    if ((r = upload(c, b.instances.data(), b.instances.size(), &di, &c->bvhAllocations)) != HRPT_OK) return r;
+    if ((r = upload(c, b.instShade.data(), b.instShade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
+    v.nodes = nullptr; v.nodeCount = b.tlasNodeCount; v.rootLeaf = b.tlasRootLeaf;      // nodeCount != 0: the walk starts at node4 0 (the instance tree)
+    v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)b.nodes4.size();
+    v.instances = reinterpret_cast<const GpuInstance*>(di); v.instanceCount = (uint32_t)b.instances.size();
+    v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.structure = HRPT_ACCEL_TWO_LEVEL;
+    c->buildInfo.instanceNodeCount = b.tlasNodeCount; c->buildInfo.distinctMeshes = b.distinctMeshes;
+    c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = 0; c->buildInfo.node4Count = v.node4Count;
+    c->buildInfo.maxDepth = 0; c->buildInfo.maxDepth4 = b.maxDepth4Tlas + b.maxDepth4Blas;
+    c->bvhNodes = v.node4Count; c->bvhTris = v.triCount;
+    c->traits.bvhMaxDepth = 0; c->traits.bvh4MaxDepth = b.maxDepth4Tlas + b.maxDepth4Blas; c->traits.twoLevelStackNeed = two_level_stack_need(b);
+    return HRPT_OK;
+}
+
 static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris, SceneView& v, bool firstBuild)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -193,7 +254,16 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
     int r;
     c->buildInfo = HrptBuildInfo{};
     c->buildInfo.requestedBuilder = (uint32_t)c->bvhBuilder;
+    c->buildInfo.structure = HRPT_ACCEL_FLAT;
+    const bool keepMeshTrees = !firstBuild && c->twoLevel != nullptr;       // hrpt_update_instances on a two-level scene
     free_acceleration(c, !firstBuild);
+    if (keepMeshTrees || (firstBuild && two_level_wanted(c, s, sceneTris))) {
+        r = build_two_level(c, s, v, keepMeshTrees);
+        c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return r;
+    }
+    v.instances = nullptr; v.instanceCount = 0; c->traits.twoLevelStackNeed = 0;
+    if (sceneTris >= (1ull << 29)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: too many triangles for the flat structure (2^29; instanced scenes of opaque materials can use HRPT_ACCEL_TWO_LEVEL)");
     uint32_t maxDepth = 0, maxDepth4 = 0;
     bool built = false;
     const int builder = c->bvhBuilder == HRPT_BVH_BUILDER_AUTO ? (sceneTris >= 65536 ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_HOST_SAH) : c->bvhBuilder;
@@ -274,7 +344,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
 // What the kernels specialise on (SceneTraits), from the library's copy of instances / materials / lights; the tree depths are kept.
 static void refresh_traits(HrptContext* c)
 {
-    SceneTraits t; t.bvhMaxDepth = c->traits.bvhMaxDepth; t.bvh4MaxDepth = c->traits.bvh4MaxDepth;
+    SceneTraits t; t.bvhMaxDepth = c->traits.bvhMaxDepth; t.bvh4MaxDepth = c->traits.bvh4MaxDepth; t.twoLevelStackNeed = c->traits.twoLevelStackNeed;
     for (const HrptPerInstanceData& in : c->keptInstances) {
         const HrptMaterialConstants& m = c->keptMaterials[in.m_MaterialIndex];
         // the transmission branch (PathTracer.hlsl:149-255) is entered for transmissive AND for BLEND materials (effective transmission
@@ -298,7 +368,7 @@ static int upload_scene_impl(HrptContext* c, const HrptSceneDesc* s)
     HIP_TRY(c, hipSetDevice(c->device));
     std::string berr;
     uint64_t sceneTris = 0;
-    if (!validate_scene(*s, sceneTris, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
+    if (!validate_scene(*s, sceneTris, berr, false)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_upload_scene: " + berr);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     c->traits = SceneTraits();
@@ -500,6 +570,7 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipSetDevice(c->device));
 
     bool wavefront = (p->flags & HRPT_FRAME_MEGAKERNEL) == 0 && wavefront_supports(c->view, p->constants);
+    if (!wavefront && c->view.instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: the megakernel does not traverse the two-level structure (hrpt_set_acceleration_structure)");
     if (!wavefront && (p->flags & HRPT_FRAME_MEGAKERNEL) == 0) c->megakernelFallbacks++;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (wavefront) {
@@ -680,6 +751,7 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
     if (!rays || !hits) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: null array");
     if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS | HRPT_RAYS_THREAD_PER_RAY))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
     if (count > (1ull << 31)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: too many rays in one call");
+    if (c->view.instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: not available on the two-level structure (hrpt_set_acceleration_structure)");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool shadow = (flags & 0xFFu) == HRPT_RAYS_SHADOW;
     // the persistent refilling traversal kernel (pt_wavefront.hip wf_trace_rays); the thread-per-ray kernel stays as the fallback for trees
@@ -725,6 +797,14 @@ int hrpt_set_shadow_overlap(HrptContext* c, int enabled)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     c->wf.serialShadow = enabled == 0;
+    return HRPT_OK;
+}
+
+int hrpt_set_acceleration_structure(HrptContext* c, int structure)
+{
+    if (!c) return HRPT_ERR_INVALID_ARGUMENT;
+    if (structure < HRPT_ACCEL_AUTO || structure > HRPT_ACCEL_TWO_LEVEL) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_set_acceleration_structure: unknown structure");
+    c->accelStructure = structure;
     return HRPT_OK;
 }
 
@@ -840,6 +920,7 @@ int hrpt_selftest_bvh(HrptContext* c, uint64_t* violations)
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     if (!violations) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_selftest_bvh: null out");
     if (!c->haveScene) return fail(c, HRPT_ERR_NO_SCENE, "hrpt_selftest_bvh: no scene uploaded");
+    if (c->view.instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_selftest_bvh: not available on the two-level structure (hrpt_set_acceleration_structure)");
     HIP_TRY(c, hipSetDevice(c->device));
     unsigned long long* d = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d, sizeof(unsigned long long)));

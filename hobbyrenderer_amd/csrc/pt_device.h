@@ -101,6 +101,14 @@ struct GpuTri {             // 48 B world-space triangle (instance transform app
 struct GpuTriAttr { float4 a, b, c, d, e; };   // a{n0,n1.x} b{n1.yz,n2.xy} c{n2.z,uv0,uv1.x} d{uv1.y,uv2,material} e{inst,prim,-,-}
 struct GpuTriTangent { float4 t0, t1, t2; };
 struct GpuInstShade { float4 adj0, adj1, adj2; };
+// Two-level structure (bvh_build.h HostInstance): one record per instance, 128 B
+struct GpuInstance {
+    float world[12];            // m_World rows 0..3, xyz each
+    float inv[12];              // inverse map, same layout (only the 3x3 part is read on the device)
+    int32_t blasRoot; uint32_t flags, material; float boxEps;
+    uint32_t mesh; float objMaxAbs, invNorm; uint32_t pad;
+};
+static_assert(sizeof(GpuInstance) == 128, "bvh_build.h HostInstance");
 struct GpuTexture {         // decoded texels of all levels (HrptTextureDesc); level l starts mipOffset[l] TEXELS after `texels`
     const uint8_t* texels; uint32_t w, h, format, mipCount;
     uint32_t mipOffset[HRPT_TEXTURE_MAX_MIPS];
@@ -119,6 +127,10 @@ struct SceneView {
     const GpuTexture* textures; uint32_t textureCount;
     const uint16_t* lutTransmittance;   // 256 x 64 RGBA16F
     const uint16_t* lutScattering;      // 256 x 128 x 32 RGBA16F
+    // two-level structure (instanced scenes; null = the flat world-space tree above): nodes4 then holds the tree over the instances
+    // (root 0, leaves ~(instance << 2)) followed by the object-space trees of the distinct meshes, tris / attrs / tangents are per MESH
+    // triangle (object space), and a hit carries its instance next to the triangle index.
+    const GpuInstance* instances; uint32_t instanceCount;
 };
 
 // ------------------------------------------------------------------ rays and hits
@@ -174,7 +186,7 @@ HRT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& r, const RayShear& s, floa
 
 // Node/triangle fetch policy: the BVH is read either from HBM/L2 (global) or from an LDS copy.
 struct GlobalBvh {
-    static constexpr int kWidth = 2;
+    static constexpr int kWidth = 2; static constexpr bool kTwoLevel = false;
     const GpuNode* nodes; const GpuTri* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const
     {
@@ -189,7 +201,7 @@ struct GlobalBvh {
 };
 
 struct GlobalBvh4 {
-    static constexpr int kWidth = 4;
+    static constexpr int kWidth = 4; static constexpr bool kTwoLevel = false;
     const GpuNode4* nodes; const GpuTri* tris;
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
     {
@@ -244,8 +256,10 @@ HRT_DEV void cswap(float& ta, int32_t& ra, float& tb, int32_t& rb)
 
 // One traversal step from inner node `cur`: tests its child boxes against [tmin, tlim], pushes the far hits (nearest on
 // top) and returns the next node reference: the nearest hit child, else the popped stack top, else kTraversalDone.
+// noi / noiF: the origin term of the near / far plane distances. They differ only inside an instance of the two-level structure, where
+// every box is widened by a per-ray object-space slack (tl_enter); everywhere else the caller passes the same value twice.
 template <class BVH, class STACK>
-HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
+HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 noiF, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
 {
     if constexpr (BVH::kWidth == 2) {
         float4 a, b, c, d; bvh.node(cur, a, b, c, d);
@@ -271,7 +285,7 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tm
         const float4 chf = bvh.row(cur, 96u);
         auto box = [&](float bnx, float bny, float bnz, float bfx, float bfy, float bfz) {
             const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(bnx, inv.x, noi.x), __builtin_fmaf(bny, inv.y, noi.y)), __builtin_fmaf(bnz, inv.z, noi.z)), tmin);
-            const float far3 = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bfx, inv.x, noi.x), __builtin_fmaf(bfy, inv.y, noi.y)), __builtin_fmaf(bfz, inv.z, noi.z));
+            const float far3 = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bfx, inv.x, noiF.x), __builtin_fmaf(bfy, inv.y, noiF.y)), __builtin_fmaf(bfz, inv.z, noiF.z));
             // the scale comes AFTER the clamp to tlim: a second triangle at exactly the distance of the best hit so far (shared edges,
             // coplanar duplicates: the tie is decided by (instance, primitive)) must survive a near distance that rounds just above tlim
             const float hi = __builtin_fminf(far3, tlim) * (1.0f + 4e-6f);
@@ -290,6 +304,12 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tm
         if (t0 < inf) return r0;
         return (sp == 0) ? kTraversalDone : stack.pop(--sp);
     }
+}
+
+template <class BVH, class STACK>
+HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 inv, float tmin, float tlim, STACK& stack, int& sp)
+{
+    return inner_step(bvh, cur, noi, noi, inv, tmin, tlim, stack, sp);
 }
 
 HRT_DEV f3 traversal_rcp(f3 d)
@@ -381,6 +401,115 @@ HRT_DEV bool any_opaque(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
     return false;
 }
 
+// ------------------------------------------------------------------ two-level traversal (instanced scenes)
+// The tree over the instances is walked with the world-space ray. At an instance leaf the lane pushes kExitBlas, switches its CULLING
+// state (inv, noi) to the ray in the instance's object space and continues in the mesh's tree; popping kExitBlas switches back. Triangles
+// are never tested in object space: a leaf transforms its three object-space vertices with m_World exactly as the flat upload does
+// (bvh_build.cpp transform_point: left to right, no FMA) and runs the same watertight test on the world ray, so the hit (t, u, v) and the
+// (t, instance, primitive) order are those of the flat path bit for bit. The object-space ray keeps the world parametrisation (its
+// direction is d * Minv, not normalised), so tlim needs no conversion.
+constexpr int32_t kExitBlas = 0x7FFFFFFE;     // stack marker; never a node index (node4 counts stay below 2^29)
+struct GlobalBvhTl : GlobalBvh4 {
+    static constexpr bool kTwoLevel = true;
+    const GpuInstance* instances;
+};
+struct TlCull { f3 inv, noi, noiF; int32_t inst; };     // inst < 0: in the tree over the instances (world space, noi == noiF)
+HRT_DEV void tl_world(TlCull& c, const Ray& r)
+{
+    c.inv = traversal_rcp(r.d); c.noi = slab_origin_term(r.o, c.inv); c.noiF = c.noi; c.inst = -1;
+}
+// Culling state inside instance I. Everything that separates the computed object-space ray from the exact image of the world ray, and
+// the object-space triangles from the (rounded) world triangles the test runs on, is bounded by `eps` and added to both sides of every
+// slab of the mesh's tree:
+//   - I.boxEps: the binary32 rounding of the transformed vertices, mapped back through |Minv| (host, bvh_build.cpp)
+//   - the rounding of o - T (half an ulp of the larger operand) and of the three products / two sums per component of (o - T) * Minv,
+//     d * Minv, and of Minv itself (rounded from binary64): 2.4e-7 relative to the operands' magnitudes times ||Minv||
+//   - the direction error acts over the parameter range in which the ray can be inside the mesh's box: t * |d'| <= objMaxAbs + |o'|
+// with a factor 4 on top. Over-estimating eps only costs culling.
+HRT_DEV void tl_enter(TlCull& c, const GpuInstance& I, int32_t inst, const Ray& r)
+{
+    const float4* w = reinterpret_cast<const float4*>(I.world);
+    const float4 w2 = w[2];                                        // {M22, T.x, T.y, T.z}
+    const float4* q = reinterpret_cast<const float4*>(I.inv);
+    const float4 q0 = q[0], q1 = q[1]; const float q22 = I.inv[8];    // rows of Minv: {a00 a01 a02 a10} {a11 a12 a20 a21} a22
+    const f3 rel = mk3(r.o.x - w2.y, r.o.y - w2.z, r.o.z - w2.w);
+    const f3 oo = mk3(__builtin_fmaf(rel.z, q1.z, __builtin_fmaf(rel.y, q0.w, rel.x * q0.x)),
+                      __builtin_fmaf(rel.z, q1.w, __builtin_fmaf(rel.y, q1.x, rel.x * q0.y)),
+                      __builtin_fmaf(rel.z, q22, __builtin_fmaf(rel.y, q1.y, rel.x * q0.z)));
+    const f3 od = mk3(__builtin_fmaf(r.d.z, q1.z, __builtin_fmaf(r.d.y, q0.w, r.d.x * q0.x)),
+                      __builtin_fmaf(r.d.z, q1.w, __builtin_fmaf(r.d.y, q1.x, r.d.x * q0.y)),
+                      __builtin_fmaf(r.d.z, q22, __builtin_fmaf(r.d.y, q1.y, r.d.x * q0.z)));
+    auto max3abs = [](f3 v) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); };
+    const float oMax = __builtin_fmaxf(max3abs(r.o), __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w2.y), __builtin_fabsf(w2.z)), __builtin_fabsf(w2.w)));
+    const float dRatio = max3abs(r.d) * I.invNorm / __builtin_fmaxf(max3abs(od), 1e-30f);
+    const float eps = I.boxEps + 4.0f * 2.4e-7f * (I.invNorm * (oMax + max3abs(rel)) + dRatio * (I.objMaxAbs + max3abs(oo)));
+    c.inv = traversal_rcp(od);
+    const f3 n = slab_origin_term(oo, c.inv);
+    const f3 e = mk3(eps * __builtin_fabsf(c.inv.x), eps * __builtin_fabsf(c.inv.y), eps * __builtin_fabsf(c.inv.z));
+    c.noi = mk3(n.x - e.x, n.y - e.y, n.z - e.z); c.noiF = mk3(n.x + e.x, n.y + e.y, n.z + e.z);
+    c.inst = inst;
+}
+// world-space vertices of object-space triangle (a, b, c) of instance I: transform_point of bvh_build.cpp (mul(float4(p,1), M).xyz, left to right)
+HRT_DEV void tl_world_triangle(const GpuInstance& I, float4 a, float4 b, float4 c, f3& p0, f3& p1, f3& p2)
+{
+    const float4* w = reinterpret_cast<const float4*>(I.world);
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2];      // {M00 M01 M02 M10} {M11 M12 M20 M21} {M22 Tx Ty Tz}
+    auto xf = [&](float x, float y, float z) {
+        return mk3(((x * w0.x + y * w0.w) + z * w1.z) + w2.y,
+                   ((x * w0.y + y * w1.x) + z * w1.w) + w2.z,
+                   ((x * w0.z + y * w1.y) + z * w2.x) + w2.w);
+    };
+    p0 = xf(a.x, a.y, a.z); p1 = xf(b.x, b.y, b.z); p2 = xf(c.x, c.y, c.z);
+}
+// One node reference of the two-level walk that is not an inner node of the current tree: the BLAS exit marker or an instance leaf.
+// Returns the next reference (and updates the culling state); triangle leaves (c.inst >= 0, cur < 0) are the caller's.
+template <class STACK>
+HRT_DEV int32_t tl_switch(const GlobalBvhTl& bvh, int32_t cur, TlCull& c, const Ray& r, STACK& stack, int& sp)
+{
+    if (cur == kExitBlas) { tl_world(c, r); return sp == 0 ? kTraversalDone : stack.pop(--sp); }
+    // instance leaf
+    const int32_t inst = (int32_t)(((uint32_t)~cur) >> 2);
+    const GpuInstance& I = bvh.instances[inst];
+    const int32_t root = I.blasRoot;
+    if (root == kTraversalDone) return sp == 0 ? kTraversalDone : stack.pop(--sp);      // mesh without triangles
+    stack.push(sp++, kExitBlas);
+    tl_enter(c, I, inst, r);
+    return root;
+}
+
+// any_opaque over the two-level structure (every instance of such a scene is opaque: pt_capi.cpp only builds it then)
+template <class STACK>
+HRT_DEV bool any_hit_two_level(const GlobalBvhTl& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, uint32_t nodeLoopMin = 0)
+{
+    if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
+    RayShear sh = make_shear(r.d);
+    TlCull c; tl_world(c, r);
+    int sp = 0; int32_t cur;
+    if (nodeCount == 0) { if (rootLeaf == 0) return false; cur = rootLeaf; }
+    else cur = 0;
+    for (;;) {
+        while (cur >= 0 && cur != kExitBlas) {
+            cur = inner_step(bvh, cur, c.noi, c.noiF, c.inv, r.tmin, r.tmax, stack, sp);
+            if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != kExitBlas)) < nodeLoopMin) break;
+        }
+        if (cur == kTraversalDone) break;
+        if (cur == kExitBlas || (cur < 0 && c.inst < 0)) { cur = tl_switch(bvh, cur, c, r, stack, sp); continue; }
+        if (cur < 0) {
+            const GpuInstance& I = bvh.instances[c.inst];
+            uint32_t enc = (uint32_t)(~cur);
+            uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                float4 ta, tb, tc; bvh.tri(first + i, ta, tb, tc);
+                f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
+                float t, u, v;
+                if (tri_test(p0, p1, p2, r, sh, t, u, v)) return true;
+            }
+            cur = stack.pop(--sp);          // never empty inside an instance: the exit marker is below
+        }
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------ triangle attributes
 // What GetTriangleVertices + UnpackVertex (RaytracingCommon.hlsli:33-50, MeshCommon.hlsli:9-22) yield for a hit,
 // read from the per-triangle record built at upload (the quantised vertex / index buffers are consumed there).
@@ -394,6 +523,14 @@ HRT_DEV TriVerts load_tri_attr(const SceneView& s, uint32_t tri)
     t.uv0.x = c.y; t.uv0.y = c.z; t.uv1.x = c.w; t.uv1.y = d.x; t.uv2.x = d.y; t.uv2.y = d.z;
     t.material = __float_as_uint(d.w); t.inst = __float_as_uint(e.x);
     return t;
+}
+// ... for a committed hit: with the two-level structure the record is per MESH triangle and the instance (hence the material) comes
+// from the hit
+HRT_DEV TriVerts load_hit_attr(const SceneView& s, const Hit& hit)
+{
+    TriVerts tv = load_tri_attr(s, hit.tri);
+    if (s.instances) { tv.inst = hit.inst; tv.material = s.instances[hit.inst].material; }
+    return tv;
 }
 // GetInterpolatedUV, RaytracingCommon.hlsli:79-89
 HRT_DEV f2 interpolated_uv(const TriVerts& tv, float bx, float by)

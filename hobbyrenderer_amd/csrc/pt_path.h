@@ -134,6 +134,7 @@ template <bool ALL_OPAQUE = false, class BVH, class STACK>
 HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, uint32_t nodeLoopMin = 0)
 {
     Ray ray = shadow_ray(worldPos, L, maxDist);
+    if constexpr (BVH::kTwoLevel) return any_hit_two_level(bvh, s.rootLeaf, s.nodeCount, ray, stack, nodeLoopMin) ? 0.0f : 1.0f;
     // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
     bool sawNonOpaque;
     if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque, nodeLoopMin)) return 0.0f;
@@ -344,7 +345,7 @@ template <bool TEX, bool TRANS, bool DIRONLY, class EMIT>
 HRT_DEV SurfaceOutcome shade_surface_a(const SceneView& s, const HrptPathTracerConstants& cb, PathState& ps, const Hit& hit,
                                        SurfaceCarry& carry, EMIT&& emit)
 {
-    TriVerts tv = load_tri_attr(s, hit.tri);                                      // inst/mesh/vertex fetch :92-94,:104 (LOD 0, :103)
+    TriVerts tv = load_hit_attr(s, hit);                                          // inst/mesh/vertex fetch :92-94,:104 (LOD 0, :103)
     GpuInstShade is = s.instShade[tv.inst];
     const HrptMaterialConstants& mat = s.materials[tv.material];
     uint32_t texFlags = TEX ? mat.m_TextureFlags : 0u;

@@ -23,6 +23,7 @@ struct SceneTraits {
     bool hasNonOpaque = false;         // some instance is ForceNonOpaque (material alpha mode MASK or BLEND)
     uint32_t bvhMaxDepth = 0;
     uint32_t bvh4MaxDepth = 0;
+    uint32_t twoLevelStackNeed = 0;    // != 0: the scene holds the two-level structure (SceneView::instances); worst-case traversal stack entries
 };
 
 struct WavefrontState {

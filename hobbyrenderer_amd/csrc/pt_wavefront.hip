@@ -46,6 +46,7 @@ struct WfBuffers {
     float4 *rayO[2], *rayD[2], *thr[2], *med0[2], *med1[2];
     uint32_t* pathCnt[2];
     float4* hit;
+    uint32_t* hitInst;         // two-level structure only: CommittedInstanceIndex of the hit in `hit` (the record's triangle index is per mesh)
     float4 *sh0, *sh1, *sh2, *sh3, *sh4, *shL;
     uint32_t* shadowCnt;
     // shadow-ray stage of scenes with non-opaque geometry: one compacted ray per valid light sample {o, tmin} {d, tmax}, the (entry, light)
@@ -133,7 +134,7 @@ struct GlobalCandidates {
 // BVH copy in LDS; W = node width (2: GpuNode, 4: GpuNode4)
 template <int W>
 struct LdsBvh {
-    static constexpr int kWidth = W;
+    static constexpr int kWidth = W; static constexpr bool kTwoLevel = false;
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
@@ -149,6 +150,8 @@ struct LdsBvh {
 };
 template <int W> struct GlobalBvhOf;
 template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV GlobalBvh make(const SceneView& s) { GlobalBvh g; g.nodes = s.nodes; g.tris = s.tris; return g; } };
+constexpr int kTwoLevelTree = 44;     // GlobalBvhOf key of the two-level structure (4-wide nodes)
+template <> struct GlobalBvhOf<kTwoLevelTree> { using type = GlobalBvhTl; static HRT_DEV GlobalBvhTl make(const SceneView& s) { GlobalBvhTl g; g.nodes = s.nodes4; g.tris = s.tris; g.instances = s.instances; return g; } };
 template <> struct GlobalBvhOf<4> { using type = GlobalBvh4; static HRT_DEV GlobalBvh4 make(const SceneView& s) { GlobalBvh4 g; g.nodes = s.nodes4; g.tris = s.tris; return g; } };
 
 // Carves dynamic LDS: [stack: min(DEPTH, 32)*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
@@ -278,16 +281,19 @@ constexpr uint32_t kRefillMinDefault = 12;
 // ANYHIT: the same persistent loop over the shadow-ray queue (sqO / sqD / sqId, sqCnt rays per segment): the first hit on an opaque
 // triangle ends the ray (kVisBlocked); otherwise the ray is clear or, if it crossed non-opaque triangles, left to wf_shadow's candidate
 // pass (kVisCandidates). Shadow rays get the lane refill closest-hit rays have: 3.8 -> 8 Grays/s on the glass config.
-template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void wf_extend(WfArgs a, uint32_t parity)
+// TL: the two-level structure of instanced scenes (pt_device.h "two-level traversal"): tree in global memory, closest hits only, every
+// instance opaque; the hit's instance goes to its own stream (hitInst) next to the hit record.
+template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, bool TL = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 : 5))) void wf_extend(WfArgs a, uint32_t parity)
 {
+    static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = ANYHIT ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kRows * kBlock * 4) + threadIdx.x;
     if (DEPTH > kExtendLdsStack) { stack.spill = a.spill[ANYHIT ? 1 : 0] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
-    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
+    typename GlobalBvhOf<(TL ? kTwoLevelTree : W)>::type gbvh = GlobalBvhOf<(TL ? kTwoLevelTree : W)>::make(a.scene);
     const SceneView& s = a.scene;
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         bool active = false;
         Ray r; r.o = mk3(0.0f, 0.0f, 0.0f); r.d = mk3(0.0f, 0.0f, 1.0f); r.tmin = 0.0f; r.tmax = 1e10f;
         RayShear sh = make_shear(r.d); f3 inv = mk3(0.0f, 0.0f, 0.0f), noi = mk3(0.0f, 0.0f, 0.0f);
+        TlCull tl; tl.inv = inv; tl.noi = noi; tl.noiF = noi; tl.inst = -1;      // TL only (dead otherwise)
         HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
         Hit best; best.valid = false; best.t = 0.0f; best.inst = 0; best.prim = 0; best.u = 0.0f; best.v = 0.0f; best.opaque = 0; best.tri = 0;
         int32_t cur = kTraversalDone; int sp = 0; uint32_t slot = 0, rng = 0, rng0 = 0; float tlim = 0.0f;
@@ -338,7 +345,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                     lower.have = false;
                     best.valid = false; tlim = r.tmax; sp = 0;
                     bool finite = (r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z);
-                    sh = make_shear(r.d); inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv);
+                    sh = make_shear(r.d);
+                    if constexpr (TL) tl_world(tl, r); else { inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv); }
                     cur = (emptyScene || !finite) ? kTraversalDone : (s.nodeCount == 0 ? s.rootLeaf : 0);
                     active = true; ++nRays;
                 }
@@ -349,14 +357,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                 // ---- descend inner nodes until this lane holds a leaf (or its stack ran out)
                 // (the descent is cut short once fewer than nodeLoopMin lanes are still at inner nodes: the rest of the wave holds leaves and
                 // would only wait; the lanes cut off keep their node and go on in the next round. Thresholded while-while.)
+                if constexpr (TL) {
+                    while (cur >= 0 && cur != kExitBlas) {
+                        cur = inner_step(gbvh, cur, tl.noi, tl.noiF, tl.inv, r.tmin, tlim, stack, sp);
+                        if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != kExitBlas)) < a.nodeLoopMin) break;
+                    }
+                    // leaving an instance / entering one: the lane continues with the next tree in the next round
+                    if (cur == kExitBlas || (cur < 0 && cur != kTraversalDone && tl.inst < 0)) cur = tl_switch(gbvh, cur, tl, r, stack, sp);
+                    else if (cur < 0 && cur != kTraversalDone) {
+                        const GpuInstance& I = s.instances[tl.inst];
+                        const uint32_t enc = (uint32_t)(~cur), first = enc >> 2, count = (enc & 3u) + 1u;
+                        const uint32_t inst = (uint32_t)tl.inst, iflags = I.flags & 7u;
+                        for (uint32_t i = 0; i < count; ++i) {
+                            float4 ta, tb, tc; gbvh.tri(first + i, ta, tb, tc);
+                            f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
+                            float t, u, v;
+                            const bool hitTri = tri_test(p0, p1, p2, r, sh, t, u, v);
+                            const uint32_t prim = __float_as_uint(tb.w);
+                            // Written as selects on one flag. The nested-if form of the flat loop below was compiled (ROCm 7.2, gfx950) to code that,
+                            // on a tie in t won by (instance, primitive), took the new key but kept the OLD barycentrics: hits on an edge shared by
+                            // two triangles then shaded with the other triangle's (u, v). tests/test_two_level_gpu.py::test_two_level_full_frame
+                            // holds such a pixel.
+                            const bool take = hitTri && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));
+                            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                            best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+                            best.opaque = take ? iflags : best.opaque;
+                            best.valid = best.valid || take;
+                            tlim = take ? t : tlim;
+                        }
+                        cur = stack.pop(--sp);      // the exit marker is below every entry pushed inside an instance
+                    }
+                } else {
                 while (cur >= 0) {
                     HRT_PHASE(ANYHIT ? PH_ANY_NODE : PH_EXT_NODE);
                     if (LDS_BVH) cur = inner_step(lbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
                     else cur = inner_step(gbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
                     if ((uint32_t)__popcll(__ballot(cur >= 0)) < a.nodeLoopMin) break;
                 }
+                }
                 // ---- intersect the leaf
-                if (cur < 0 && cur != kTraversalDone) {
+                if (!TL && cur < 0 && cur != kTraversalDone) {
                     uint32_t enc = (uint32_t)(~cur);
                     uint32_t first = enc >> 2, count = (enc & 3u) + 1u;
                     HRT_PHASE(ANYHIT ? PH_ANY_LEAF : PH_EXT_LEAF);
@@ -412,6 +452,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                         if (a.hasStochasticAlpha && rng != rng0) { float4 d = rayD[slot]; d.w = __uint_as_float(rng); rayD[slot] = d; }
                         // hit record: triangle (< 2^29: leaf references hold first << 2) | shading class << 29; 0xFFFFFFFF = miss
                         a.b.hit[slot] = make_float4(best.t, best.u, best.v, __uint_as_float(best.valid ? (best.tri | ((best.opaque >> 1) << 29)) : 0xFFFFFFFFu));
+                        if constexpr (TL) a.b.hitInst[slot] = best.inst;
                         active = false;
                     }
                 }
@@ -673,7 +714,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
                 if (tri != 0xFFFFFFFFu) {
                     HRT_PHASE(PH_SHADE_HIT);
-                    Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = 0; h.opaque = 1;
+                    Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = s.instances ? a.b.hitInst[slot] : 0u; h.opaque = 1;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
                     SurfaceOutcome oc = shade_surface_a<!SIMPLE, !SIMPLE, SIMPLE>(s, cb, ps, h, carry, [&](uint32_t li, float ux, float uy) {
                         if (STREAMED) ++nNee;
@@ -870,9 +911,10 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
 enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadowSlim = 3 };
 // (the buffered variant is held at 3 waves per SIMD: the gradient-sampled alpha test of mip-mapped MASK textures -- a rare path -- would
 // otherwise raise its register count past 170 and cost every scene with alpha-tested geometry a wave of occupancy)
-template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE>
+template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, bool TL = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
+    static_assert(!TL || (!LDS_BVH && W == 4 && (MODE == kShadowOpaque || MODE == kShadowSlim)), "two-level structure: opaque any-hit query over the global tree");
     constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;
     constexpr bool SLIM = MODE == kShadowSlim;
     constexpr int kLdsMax = MODE == kShadowResolve ? kExtendLdsStack : kShadowLdsStack;
@@ -882,7 +924,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     if (DEPTH > kLdsMax) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
     LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kLdsMax>::kRows * kBlock * 4) + threadIdx.x;
-    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
+    typename GlobalBvhOf<(TL ? kTwoLevelTree : W)>::type gbvh = GlobalBvhOf<(TL ? kTwoLevelTree : W)>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
     const float sunIntensity = s.lights[0].m_Intensity;      // g_Lights[0], PathTracer.hlsl:137 (reference quirk kept)
@@ -1052,7 +1094,7 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 }
 
 // ------------------------------------------------------------------ host side
-struct Variant { bool lds; int depth; int width; size_t ldsBytes; };
+struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; };
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
@@ -1088,12 +1130,30 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
         if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     }
 }
+template <int D> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
+{
+    if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
+}
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit = false)
 {
+    if (v.twoLevel) {       // closest hits only (wavefront_render keeps the any-hit pass off for two-level scenes)
+        if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
+        else if (v.depth <= 32) hipLaunchKernelGGL((wf_extend<false, 32, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
+        else hipLaunchKernelGGL((wf_extend<false, 64, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
+        return;
+    }
     if (v.lds) launch_extend_l<true>(v, g, sh, st, a, parity, anyHit); else launch_extend_l<false>(v, g, sh, st, a, parity, anyHit);
 }
 void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
+    if (v.twoLevel) {
+        if (v.depth <= 16) launch_shadow_two_level<16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        else if (v.depth <= 32) launch_shadow_two_level<32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        else launch_shadow_two_level<64>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        return;
+    }
     if (v.lds) launch_shadow_l<true>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_l<false>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
 }
 
@@ -1109,6 +1169,8 @@ template <bool L, bool SH> void launch_trace_rays_d(int depth, dim3 g, size_t ld
     if (depth <= 16) launch_trace_rays_t<L, 16, SH>(g, lds, st, a); else if (depth <= 32) launch_trace_rays_t<L, 32, SH>(g, lds, st, a); else launch_trace_rays_t<L, 64, SH>(g, lds, st, a);
 }
 }
+
+
 
 bool wavefront_trace_rays_supported(const SceneTraits& traits) { return 3 * traits.bvh4MaxDepth + 2 <= kMaxStackNeed; }
 
@@ -1247,7 +1309,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // batch the accumulation indices so that one batch stays below maxSamples AND its queue pool below a byte budget: the pool takes
     // 240 B per sample with one light and no medium, but ~1.2 KB with 8 lights and non-opaque geometry (shadow-ray queue + candidate lists)
     const uint32_t maxLights = constants.m_LightCount ? constants.m_LightCount : 1;
-    const uint64_t bytesPerSample = 16ull * (2 * (3 + (traits.hasMedium ? 2 : 0)) + 1 + 5 + maxLights + 1) +
+    const uint64_t bytesPerSample = 16ull * (2 * (3 + (traits.hasMedium ? 2 : 0)) + 1 + 5 + maxLights + 1) + (scene.instances ? 4 : 0) +
                                     ((traits.hasNonOpaque || maxLights > 1) ? (16ull + 16 + 4 + 4 + 8 * kShadowCandidates) * maxLights : 0);
     uint32_t sppPerBatch = accumCount < kMaxSppPerBatch ? accumCount : kMaxSppPerBatch;
     uint64_t maxSamples = st.maxSamplesPerBatch ? st.maxSamplesPerBatch : (64ull << 20);
@@ -1275,6 +1337,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         oCnt[p] = carve((size_t)segs * 4);
     }
     size_t oHit = carve(capacity * 16);
+    const size_t oHitInst = scene.instances ? carve(capacity * 4) : 0;
     size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16), oSh2 = carve(capacity * 16), oSh3 = carve(capacity * 16), oSh4 = carve(capacity * 16);
     size_t oShL = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
@@ -1300,7 +1363,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         a.b.rayO[p] = (float4*)(base + oRayO[p]); a.b.rayD[p] = (float4*)(base + oRayD[p]); a.b.thr[p] = (float4*)(base + oThr[p]);
         a.b.med0[p] = (float4*)(base + oMed0[p]); a.b.med1[p] = (float4*)(base + oMed1[p]); a.b.pathCnt[p] = (uint32_t*)(base + oCnt[p]);
     }
-    a.b.hit = (float4*)(base + oHit);
+    a.b.hit = (float4*)(base + oHit); a.b.hitInst = scene.instances ? (uint32_t*)(base + oHitInst) : nullptr;
     a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1); a.b.sh2 = (float4*)(base + oSh2); a.b.sh3 = (float4*)(base + oSh3);
     a.b.sh4 = (float4*)(base + oSh4); a.b.shL = (float4*)(base + oShL);
     a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
@@ -1327,6 +1390,12 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const size_t candBytes = traits.hasNonOpaque ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     auto pick = [&](int width, size_t extraBytes, int ldsStackMax) {
         Variant v; v.width = width;
+        if (traits.twoLevelStackNeed) {      // two-level structure: 4-wide trees in global memory, its own kernels
+            v.width = 4; v.twoLevel = true; v.lds = false;
+            v.depth = traits.twoLevelStackNeed <= 16 ? 16 : (traits.twoLevelStackNeed <= 32 ? 32 : 64);
+            v.ldsBytes = (size_t)(v.depth > ldsStackMax ? ldsStackMax : v.depth) * kBlock * 4 + st.padLdsBytes;
+            return v;
+        }
         if (v.width == 4 && 3 * traits.bvh4MaxDepth + 2 > kMaxStackNeed) v.width = 2;
         if (v.width == 2) v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : (traits.bvhMaxDepth + 2 <= 32 ? 32 : 64));
         else v.depth = 3 * traits.bvh4MaxDepth + 2 <= 16 ? 16 : (3 * traits.bvh4MaxDepth + 2 <= 32 ? 32 : 64);
@@ -1351,6 +1420,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     int shadowMode = (!vS.lds && unevenRays) ? kShadowResolve : selfMode;
     if (st.shadowPath == 1) shadowMode = selfMode;
     if (st.shadowPath == 2 && (traits.hasNonOpaque || maxLights > 1)) shadowMode = kShadowResolve;
+    if (traits.twoLevelStackNeed) shadowMode = kShadowOpaque;      // every instance of a two-level scene is opaque; no any-hit pass over that structure
     // any-hit pass over the shadow rays (same kernel family as vE). wf_extend<ANYHIT> always carves its candidate columns out of LDS
     // (launch_extend_t adds them to the launch), opaque scene or not, so the budget check must count them too.
     const Variant vA = pick(forced ? forced : 4, (size_t)kShadowCandidates * 2 * kBlock * 4, kExtendLdsStack);
@@ -1371,7 +1441,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : ((st.serialShadow && !vE.lds) ? 8 : 16);
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
         // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part
-        const uint32_t worst = vE.width == 4 || vS.width == 4 ? 3 * traits.bvh4MaxDepth + 2 : traits.bvhMaxDepth + 2;
+        const uint32_t worst = traits.twoLevelStackNeed ? traits.twoLevelStackNeed : (vE.width == 4 || vS.width == 4 ? 3 * traits.bvh4MaxDepth + 2 : traits.bvhMaxDepth + 2);
         const uint32_t entries = worst > (uint32_t)kExtendLdsStack ? worst - kExtendLdsStack : 1u;
         const size_t threads = (size_t)cus * blocksPerCu * kBlock, bytes = 2 * threads * entries * 4;
         if (bytes > st.spillBytes) {

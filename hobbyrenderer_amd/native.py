@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_acceleration_structure", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere",
 ]
 
@@ -53,6 +53,7 @@ lib.hrpt_resolve_columns_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, 
 lib.hrpt_get_stats.argtypes = [C.c_void_p, C.POINTER(S.Stats)]
 lib.hrpt_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
 lib.hrpt_set_shadow_overlap.argtypes = [C.c_void_p, C.c_int]
+lib.hrpt_set_acceleration_structure.argtypes = [C.c_void_p, C.c_int]
 lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
 lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
@@ -202,6 +203,11 @@ class PathTracerContext:
     def set_bvh_builder(self, builder):
         """S.BVH_BUILDER_AUTO (default: host SAH below 65 536 triangles, GPU PLOC above), _HOST_SAH, _GPU_LBVH or _GPU_PLOC; used by the next upload_scene / update_instances."""
         self._check(lib.hrpt_set_bvh_builder(self._h, int(builder)))
+
+    def set_acceleration_structure(self, structure):
+        """S.ACCEL_AUTO (default), S.ACCEL_FLAT (one world-space tree) or S.ACCEL_TWO_LEVEL (a tree per distinct mesh + a tree over the instances;
+        opaque scenes only, otherwise the flat tree is built -- build_info().structure tells); used by the next upload_scene."""
+        self._check(lib.hrpt_set_acceleration_structure(self._h, int(structure)))
 
     def update_instances(self, instances, first=0):
         """New transforms for the instances [first, first + len(instances)) (PerInstanceData records); rebuilds the acceleration structure."""

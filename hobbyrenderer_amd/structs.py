@@ -134,14 +134,16 @@ RayHit = np.dtype([("t", f32), ("u", f32), ("v", f32), ("instance", u32), ("prim
 RAYS_CLOSEST, RAYS_SHADOW, RAYS_DEVICE_POINTERS, RAYS_THREAD_PER_RAY = 0, 1, 0x100, 0x200
 
 
-class BuildInfo(C.Structure):      # HrptBuildInfo, 48 B
+class BuildInfo(C.Structure):      # HrptBuildInfo, 64 B
     _fields_ = [("requestedBuilder", C.c_uint32), ("usedBuilder", C.c_uint32), ("buildMs", C.c_float), ("deviceBuildMs", C.c_float),
                 ("triangleCount", C.c_uint32), ("nodeCount", C.c_uint32), ("node4Count", C.c_uint32), ("maxDepth", C.c_uint32),
-                ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("pad", C.c_uint32 * 1)]
+                ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("structure", C.c_uint32),
+                ("instanceNodeCount", C.c_uint32), ("distinctMeshes", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 ABI_VERSION = 3                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)
 BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC, BVH_BUILDER_AUTO = 0, 1, 2, 3
+ACCEL_AUTO, ACCEL_FLAT, ACCEL_TWO_LEVEL = 0, 1, 2     # HRPT_ACCEL_* (hrpt_set_acceleration_structure)
 
 
 def default_material():

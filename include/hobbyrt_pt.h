@@ -318,9 +318,30 @@ typedef struct HrptBuildInfo {
     uint32_t triangleCount, nodeCount, node4Count, maxDepth, maxDepth4;
     uint32_t mortonBits;                        /* GPU builder: Morton bits of the hierarchy (63 unless the full-code tree was too deep) */
     float    sahCost;                           /* surface-area-heuristic cost of the 2-wide tree: 1 + sum(area(child) * (inner ? 1 : triangles)) / area(root) */
-    uint32_t pad[1];
-} HrptBuildInfo;                                /* 48 B */
+    uint32_t structure;                         /* HRPT_ACCEL_FLAT or HRPT_ACCEL_TWO_LEVEL: what the last build produced */
+    uint32_t instanceNodeCount;                 /* two-level: 4-wide nodes of the tree over the instances (node4Count counts those + the mesh trees) */
+    uint32_t distinctMeshes;                    /* two-level: meshes with a tree of their own (triangleCount counts THEIR triangles, not instances x triangles) */
+    uint32_t pad[2];
+} HrptBuildInfo;                                /* 64 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
+
+/* Shape of the acceleration structure. The reference builds one BLAS per mesh and a TLAS over the instances (src/Scene.cpp:98-154).
+ * HRPT_ACCEL_FLAT (what AUTO picks for all but heavily instanced scenes) transforms every instance's triangles to world space once
+ * and builds ONE tree: no ray transform, one tree walk -- the fastest traversal while the tree stays cache-resident, but memory and build
+ * time grow with instances x triangles (~600 B per world triangle with the GPU builders' buffers). HRPT_ACCEL_TWO_LEVEL keeps one object-space tree per distinct mesh plus a tree over the
+ * instances: memory grows with distinct triangles + instances, hrpt_update_instances rebuilds only the small instance tree (the
+ * reference's per-frame TLAS build), traversal pays a ray transform per visited instance. Radiance is identical: hits are still
+ * decided in world space on the world-space vertices the flat upload would produce. Two-level needs every instance material to be
+ * OPAQUE (no any-hit candidates) and runs on the wavefront pipeline only (HRPT_FRAME_MEGAKERNEL, hrpt_trace_rays and hrpt_selftest_bvh
+ * answer HRPT_ERR_INVALID_ARGUMENT on such a scene); a scene that does not qualify is built flat whatever was asked -- HrptBuildInfo::
+ * structure tells. AUTO: two-level when the scene qualifies, has at least 2 M world triangles and at least 8 instances per distinct mesh
+ * on average (measured on MI355X, spheres / cylinders of ~400 triangles, 1920x1080, 8 spp, 4 bounces: 4 096 instances 19.7 ms flat vs
+ * 19.0 ms two-level, 16 384: 27.7 vs 20.2 ms, 65 536: 44.0 vs 21.5 ms and 17.6 GB vs 30 MB -- the small trees stay in cache).
+ * Takes effect at the next hrpt_upload_scene. */
+#define HRPT_ACCEL_AUTO      0
+#define HRPT_ACCEL_FLAT      1
+#define HRPT_ACCEL_TWO_LEVEL 2
+int  hrpt_set_acceleration_structure(HrptContext* ctx, int structure);
 
 /* Moving objects: writes instances[0..count) over the scene's instances [firstInstance, firstInstance + count) -- the closed dirty range
  * Renderer::UploadDirtyInstanceTransforms copies into m_InstanceDataBuffer / m_RTInstanceDescBuffer (src/Renderer.cpp:924-967, fed by

@@ -1,0 +1,202 @@
+"""Two-level acceleration structure (hrpt_set_acceleration_structure, the reference's BLAS-per-mesh + TLAS form, src/Scene.cpp:98-154)
+against the flat world-space tree: the same frames, bit for bit, and the same ray counts.
+
+The flat path is what the oracle parity tests pin (tests/test_parity_gpu.py); one case here also goes to the oracle directly.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from hobbyrenderer_amd import scenes, structs as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot(rng):
+    """Random rotation (row-vector convention does not matter for a random one)."""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)],
+                     [2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w)],
+                     [2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, masked=False, far=0.0):
+    """Floor + n_side^2 instances of two meshes (a sphere and a capped-less cylinder) with random rotations, non-uniform scales and a few
+    materials; `far` shifts the whole scene away from the origin (large world coordinates against small object coordinates)."""
+    rng = np.random.default_rng(seed)
+    b = scenes.SceneBuilder()
+    quad = b.add_mesh(*scenes.generate_floor_quad())
+    sphere = b.add_mesh(*scenes.mesh_sphere(24, 12, 0.5))
+    cyl = b.add_mesh(*scenes.mesh_cylinder(20, 6, 0.35, 1.0, bulge=0.1))
+    mats = [b.add_material(m_BaseColor=(0.8, 0.8, 0.8, 1)),
+            b.add_material(m_BaseColor=(0.7, 0.2, 0.15, 1), m_RoughnessMetallic=(0.4, 0.0)),
+            b.add_material(m_BaseColor=(0.9, 0.7, 0.2, 1), m_RoughnessMetallic=(0.25, 1.0)),
+            b.add_material(m_BaseColor=(0.2, 0.3, 0.8, 1), m_EmissiveFactor=(0.5, 0.6, 2.0, 1))]
+    if textured:
+        tex = b.add_texture(scenes.procedural_texture(rng, 64, "albedo"))
+        mats.append(b.add_material(m_BaseColor=(1, 1, 1, 1), m_TextureFlags=S.TEXFLAG_ALBEDO, m_AlbedoTextureIndex=tex))
+    if masked:
+        tex = b.add_texture(scenes.procedural_texture(rng, 64, "alpha"))
+        mats.append(b.add_material(m_BaseColor=(1, 1, 1, 1), m_TextureFlags=S.TEXFLAG_ALBEDO, m_AlbedoTextureIndex=tex,
+                                   m_AlphaMode=S.ALPHA_MODE_MASK, m_AlphaCutoff=0.5))
+    span = 1.4 * n_side
+    b.add_instance(quad, mats[0], scenes._mat((span + 4, 1, span + 4), None, (far, 0, far)))
+    for i in range(n_side):
+        for j in range(n_side):
+            mesh = sphere if (i + j) % 3 else cyl
+            sc = rng.uniform(0.5, 1.3, 3)
+            t = (far + (i - n_side / 2 + 0.5) * 1.4 + rng.uniform(-0.2, 0.2), 0.45 + rng.uniform(0, 1.5), far + (j - n_side / 2 + 0.5) * 1.4 + rng.uniform(-0.2, 0.2))
+            b.add_instance(mesh, mats[int(rng.integers(len(mats)))], scenes._mat(tuple(sc), _rot(rng), t))
+    if lights == "three":
+        b.add_light(S.LIGHT_POINT, position=(far + 1.0, 3.0, far - 1.0), color=(1.0, 0.9, 0.8), intensity=30.0, radius=0.05, range_=30.0)
+        b.add_light(S.LIGHT_SPOT, position=(far - 2.0, 4.0, far + 1.0), direction=(0.3, -1.0, -0.2), color=(0.6, 0.7, 1.0), intensity=60.0,
+                    radius=0.02, inner=0.4, outer=0.8)
+    return b.finalize(luts)
+
+
+def _camera(w, h, n_side, far=0.0):
+    d = 0.9 * n_side
+    return scenes.planar_view(w, h, position=(far + 0.3, 0.45 * d + 1.0, far - d), yaw=0.0, pitch=0.45)
+
+
+def _render(luts, sc, structure, w, h, spp, bounces, view, pos, update=None, builder=None):
+    from hobbyrenderer_amd.native import PathTracerContext
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(structure)
+        if builder is not None:
+            c.set_bvh_builder(builder)
+        c.upload_scene(sc)
+        if update is not None:
+            c.update_instances(update)
+        info = c.build_info()
+        c.resize(w, h)
+        c.reset_stats()
+        c.render(scenes.fill_constants(view, pos, sc, 0, bounces), accum_count=spp, flags=S.FRAME_DEFAULT)
+        acc = c.read_accumulation()
+        st = c.stats()
+        return acc, (int(st.closestRays), int(st.shadowRays), int(st.paths)), info, int(st.megakernelFallbacks)
+    finally:
+        c.close()
+
+
+def _same_frames(luts, sc, w, h, spp, bounces, view, pos, update=None):
+    a_flat, n_flat, i_flat, _ = _render(luts, sc, S.ACCEL_FLAT, w, h, spp, bounces, view, pos, update)
+    a_two, n_two, i_two, fb = _render(luts, sc, S.ACCEL_TWO_LEVEL, w, h, spp, bounces, view, pos, update)
+    assert i_flat.structure == S.ACCEL_FLAT and i_two.structure == S.ACCEL_TWO_LEVEL and fb == 0
+    assert n_flat == n_two, (n_flat, n_two)
+    diff = np.count_nonzero(a_flat.view(np.uint32) != a_two.view(np.uint32))
+    assert diff == 0, f"{diff} floats differ between the flat and the two-level structure"
+    assert np.isfinite(a_flat).all() and a_flat[..., :3].max() > 0
+    return i_flat, i_two
+
+
+@pytest.mark.parametrize("lights,textured", [("sun", False), ("three", False), ("sun", True), ("three", True)],
+                         ids=["sun-constants", "three-lights", "sun-textured", "three-lights-textured"])
+def test_two_level_equals_flat(luts, lights, textured):
+    """All four wf_shade / wf_shadow variant families an opaque scene can select: SIMPLE + slim shadow entries, many lights (general shade,
+    opaque any-hit over every light type), textured (general shade with the class sort)."""
+    n = 12
+    sc = instanced_scene(luts, n, lights=lights, textured=textured)
+    view, pos = _camera(192, 128, n)
+    i_flat, i_two = _same_frames(luts, sc, 192, 128, 3, 5, view, pos)
+    assert i_two.distinctMeshes == 3 and i_two.triangleCount < i_flat.triangleCount / 20
+    assert i_two.instanceNodeCount > 0 and i_two.node4Count > i_two.instanceNodeCount
+
+
+def test_two_level_far_from_the_origin(luts):
+    """World coordinates around 5000 against object coordinates below 1: the object-space culling slack (tl_enter) has to cover the binary32
+    rounding of the world-space vertices, or grazing hits are lost."""
+    n = 10
+    sc = instanced_scene(luts, n, seed=11, far=5000.0)
+    view, pos = _camera(160, 96, n, far=5000.0)
+    _same_frames(luts, sc, 160, 96, 2, 4, view, pos)
+
+
+def test_two_level_large_instance_count(luts):
+    """64 x 64 instances (1.2 M world triangles from under 600 distinct ones): deep instance tree, stack overflow columns in use."""
+    n = 64
+    sc = instanced_scene(luts, n, seed=3)
+    view, pos = _camera(256, 144, n)
+    i_flat, i_two = _same_frames(luts, sc, 256, 144, 2, 4, view, pos)
+    assert i_flat.triangleCount > 1000000 and i_two.triangleCount < 2000
+
+
+def test_two_level_full_frame(luts):
+    """1920 x 1080 over 4096 instances: two million primary rays find the rare cases -- pixel (1572, 912) hits an edge shared by two triangles
+    of a sphere at exactly the same t from both (the (instance, primitive) order decides, and the barycentrics have to be the winner's)."""
+    n = 64
+    sc = instanced_scene(luts, n, seed=3)
+    view, pos = _camera(1920, 1080, n)
+    _same_frames(luts, sc, 1920, 1080, 1, 2, view, pos)
+
+
+def test_two_level_update_instances_rebuilds_only_the_instance_tree(luts):
+    n = 12
+    sc = instanced_scene(luts, n, seed=9)
+    view, pos = _camera(160, 96, n)
+    moved = sc.instances.copy()
+    rng = np.random.default_rng(1)
+    moved["m_World"][1:, 3, :3] += rng.uniform(-0.3, 0.3, (len(moved) - 1, 3)).astype(np.float32)     # row-vector convention: translation in row 3
+    _same_frames(luts, sc, 160, 96, 2, 4, view, pos, update=moved)
+
+
+def test_two_level_matches_the_oracle(luts):
+    from oracle.binding import Oracle, OrStats
+    n = 6
+    sc = instanced_scene(luts, n, seed=21, lights="three")
+    w, h, spp, bounces = 96, 64, 2, 4
+    view, pos = _camera(w, h, n)
+    acc, counts, info, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, w, h, spp, bounces, view, pos)
+    assert info.structure == S.ACCEL_TWO_LEVEL
+    o = Oracle(sc)
+    ost = OrStats()
+    oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, bounces), w, h, spp, first_index=0, stats=ost)
+    o.close()
+    assert counts == (ost.closestRays, ost.shadowRays, ost.paths)
+    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+
+
+def test_scene_with_alpha_tested_instances_is_built_flat(luts):
+    """Two-level needs every instance ForceOpaque; asking for it on a scene with MASK materials yields the flat tree (and correct frames)."""
+    n = 6
+    sc = instanced_scene(luts, n, seed=2, masked=True)
+    view, pos = _camera(96, 64, n)
+    a_flat, n_flat, _, _ = _render(luts, sc, S.ACCEL_FLAT, 96, 64, 2, 3, view, pos)
+    a_two, n_two, info, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, 96, 64, 2, 3, view, pos)
+    assert info.structure == S.ACCEL_FLAT
+    assert n_flat == n_two and np.array_equal(a_flat.view(np.uint32), a_two.view(np.uint32))
+
+
+def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
+    from hobbyrenderer_amd.native import PathTracerContext, HrptError
+    n = 4
+    sc = instanced_scene(luts, n)
+    view, pos = _camera(64, 64, n)
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(S.ACCEL_TWO_LEVEL)
+        c.upload_scene(sc)
+        c.resize(64, 64)
+        with pytest.raises(HrptError):
+            c.render(scenes.fill_constants(view, pos, sc, 0, 2), accum_count=1, flags=S.FRAME_MEGAKERNEL)
+        with pytest.raises(HrptError):
+            c.selftest_bvh()
+        rays = np.zeros(4, S.Ray)
+        rays["direction"] = (0, 0, 1)
+        rays["tmax"] = 10
+        with pytest.raises(HrptError):
+            c.trace_rays(rays)
+        # a material change that makes an instance non-opaque rebuilds the structure flat
+        m = sc.materials.copy()
+        m["m_AlphaMode"][1] = S.ALPHA_MODE_BLEND
+        m["m_BaseColor"][1, 3] = 0.5
+        c.update_materials(m)
+        assert c.build_info().structure == S.ACCEL_FLAT
+        c.render(scenes.fill_constants(view, pos, sc, 0, 2), accum_count=1, flags=S.FRAME_MEGAKERNEL)
+        c.synchronize()
+    finally:
+        c.close()
