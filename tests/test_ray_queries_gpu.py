@@ -103,3 +103,70 @@ def test_trace_rays_argument_checks(luts):
         assert lib.hrpt_trace_rays(ctx._h, None, hits.ctypes.data, 2, 0) == -1
     finally:
         ctx.close()
+
+
+def _tiled_floor(luts, n, reverse_every=2, seed=0):
+    """n x n unit quads in the plane y = 0, each its own mesh of two triangles that share a diagonal; dyadic coordinates, so a vertical ray
+    through a point of a diagonal (or of a quad boundary, or a corner shared by up to eight triangles) gives EXACTLY the same t from every
+    triangle it touches: the (instance, primitive) order decides, and the barycentrics reported have to be the winner's. Half the meshes list
+    their triangles in the other order, and the instances are shuffled, so the winner is met first in some leaves and last in others."""
+    rng = np.random.default_rng(seed)
+    b = scenes.SceneBuilder()
+    mat = b.add_material(m_BaseColor=(0.8, 0.8, 0.8, 1))
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]], np.float32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (4, 1))
+    uv = pos[:, [0, 2]].copy()
+    verts = scenes.quantize_vertices(pos, nrm, uv, np.tile(np.array([[1, 0, 0]], np.float32), (4, 1)))
+    meshes = [b.add_mesh(verts, np.array(ix, np.uint32)) for ix in ([0, 2, 1, 0, 3, 2], [0, 3, 2, 0, 2, 1], [1, 3, 0, 1, 2, 3], [1, 2, 3, 1, 3, 0])]
+    cells = [(i, j) for i in range(n) for j in range(n)]
+    rng.shuffle(cells)
+    for k, (i, j) in enumerate(cells):
+        b.add_instance(meshes[(k // reverse_every) % 4], mat, scenes._mat((1, 1, 1), None, (i - n // 2, 0, j - n // 2)))
+    return b.finalize(luts)
+
+
+@pytest.mark.parametrize("n", [3, 12, 40], ids=["9-quads-lds", "144-quads", "1600-quads-global"])
+def test_exact_ties_on_shared_edges_and_corners(luts, n):
+    """Every kernel that keeps a closest hit (persistent wf_trace_rays over an LDS-resident or a global 4-wide tree, the thread-per-ray kernel
+    over the 2-wide tree) on rays that hit shared edges and corners exactly: winner and barycentrics as the oracle's (which is brute-force
+    checked here as well)."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    from oracle.binding import Oracle
+    sc = _tiled_floor(luts, n)
+    half = n // 2
+    ks = np.arange(-half * 8, (n - half) * 8 + 1, dtype=np.float32) / np.float32(8)      # multiples of 1/8: integers are quad boundaries
+    xs, zs = np.meshgrid(ks, ks)
+    pts = np.stack([xs.ravel(), zs.ravel()], 1)
+    frac = pts - np.floor(pts)
+    special = (frac[:, 0] == frac[:, 1]) | (frac[:, 0] + frac[:, 1] == 1) | (frac[:, 0] == 0) | (frac[:, 1] == 0)
+    pts = pts[special]
+    if len(pts) > 6000:
+        pts = pts[np.random.default_rng(1).choice(len(pts), 6000, replace=False)]
+    rays = np.zeros(len(pts), S.Ray)
+    rays["origin"][:, 0], rays["origin"][:, 1], rays["origin"][:, 2] = pts[:, 0], 2.0, pts[:, 1]
+    rays["direction"] = (0, -1, 0)
+    rays["tmax"] = 1e10
+    ctx = PathTracerContext(0)
+    o = Oracle(sc)
+    try:
+        ctx.upload_scene(sc)
+        got = {"persistent": ctx.trace_rays(rays), "thread per ray": ctx.trace_rays(rays, thread_per_ray=True)}
+        ties = 0
+        for i, r in enumerate(rays):
+            ok, inst, prim, u, v, t, _ = o.trace_standard(r["origin"], r["direction"], 0.0, 1e10, 0)
+            inside = (-half <= pts[i, 0] <= n - half) and (-half <= pts[i, 1] <= n - half)
+            assert ok == inside, i
+            if not ok:
+                continue
+            if i % 16 == 0:
+                bf = o.trace_closest(r["origin"], r["direction"], brute_force=True)
+                assert bf[:2] == (inst, prim) and np.float32(bf[2]) == np.float32(u) and np.float32(bf[3]) == np.float32(v), i
+            ties += 1
+            for name, hits in got.items():
+                h = hits[i]
+                assert h["hit"] and (int(h["instance"]), int(h["primitive"])) == (inst, prim), (name, i, pts[i])
+                assert np.float32(h["t"]) == np.float32(t) and np.float32(h["u"]) == np.float32(u) and np.float32(h["v"]) == np.float32(v), (name, i, pts[i], h, (u, v))
+        assert ties > 100
+    finally:
+        o.close()
+        ctx.close()
