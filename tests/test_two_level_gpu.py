@@ -23,13 +23,13 @@ def _rot(rng):
                      [2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, masked=False, far=0.0):
+def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, masked=False, far=0.0, sphere_res=(24, 12)):
     """Floor + n_side^2 instances of two meshes (a sphere and a capped-less cylinder) with random rotations, non-uniform scales and a few
     materials; `far` shifts the whole scene away from the origin (large world coordinates against small object coordinates)."""
     rng = np.random.default_rng(seed)
     b = scenes.SceneBuilder()
     quad = b.add_mesh(*scenes.generate_floor_quad())
-    sphere = b.add_mesh(*scenes.mesh_sphere(24, 12, 0.5))
+    sphere = b.add_mesh(*scenes.mesh_sphere(sphere_res[0], sphere_res[1], 0.5))
     cyl = b.add_mesh(*scenes.mesh_cylinder(20, 6, 0.35, 1.0, bulge=0.1))
     mats = [b.add_material(m_BaseColor=(0.8, 0.8, 0.8, 1)),
             b.add_material(m_BaseColor=(0.7, 0.2, 0.15, 1), m_RoughnessMetallic=(0.4, 0.0)),
@@ -132,6 +132,16 @@ def test_two_level_full_frame(luts):
     sc = instanced_scene(luts, n, seed=3)
     view, pos = _camera(1920, 1080, n)
     _same_frames(luts, sc, 1920, 1080, 1, 2, view, pos)
+
+
+def test_4096_instances_of_a_25k_triangle_mesh(luts):
+    """4 096 instances of a 25 k-triangle mesh upload without flattening (70 M world triangles from 26 k distinct
+    ones), image bit-exact against the flat structure of the same scene."""
+    n = 64
+    sc = instanced_scene(luts, n, seed=4, sphere_res=(160, 80))
+    view, pos = _camera(480, 270, n)
+    i_flat, i_two = _same_frames(luts, sc, 480, 270, 2, 3, view, pos)
+    assert i_flat.triangleCount > 60_000_000 and i_two.triangleCount < 30_000 and i_two.distinctMeshes == 3
 
 
 def test_two_level_update_instances_rebuilds_only_the_instance_tree(luts):
