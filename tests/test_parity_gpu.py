@@ -259,6 +259,31 @@ def test_forced_bvh_width(luts, width, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("sort", [0, 1], ids=["unsorted", "sorted"])
+def test_shade_class_sort_forced_on_and_off(luts, sort, monkeypatch):
+    """wf_shade's general variants shade a segment grouped by shading class (constants / textured / transmission; HRPT_WF_SHADE_SORT, read at
+    hrpt_create; default: only when the scene samples textures). The order inside a segment must not change a bit: glass (two classes, sort off
+    by default), the textured Sponza-class scene (three classes, on by default), a soup with every material class, more lights than the buffered
+    variant holds (streamed light loop + sort)."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    monkeypatch.setenv("HRPT_WF_SHADE_SORT", str(sort))
+    c = PathTracerContext(0)
+    try:
+        sc, view, pos, cfg = scenes.config_glass(luts, 128, 72, detail=0.5)
+        _assert_parity(*_run_both(c, sc, view, pos, 128, 72, 3, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_sponza_class(luts, 128, 72, detail=0.5, tex_size=32)
+        _assert_parity(*_run_both(c, sc, view, pos, 128, 72, 3, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+        sc = random_soup(luts, 600, 14, 0.5, 0.3, True)
+        view, pos = scenes.planar_view(96, 64, position=(0.2, 0.3, -5.0), aspect=1.5)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 64, 3, 8, S.FRAME_WAVEFRONT))
+        sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)
+        sc = _many_lights(sc, 11)
+        _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, 5, S.FRAME_WAVEFRONT))
+        assert c.stats().megakernelFallbacks == 0
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("path", [1, 2], ids=["buffered", "anyhit_resolve"])
 def test_forced_shadow_path(luts, path, monkeypatch):
     """Scenes with non-opaque geometry take one of two shadow-ray schedules (HRPT_WF_SHADOW_PATH, read at hrpt_create): wf_shadow's own
