@@ -158,6 +158,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     if (const char* e = getenv("HRPT_WF_SHADOW_PATH")) c->wf.shadowPath = atoi(e);
     if (const char* e = getenv("HRPT_WF_SHADE_SORT")) c->wf.shadeSort = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("HRPT_WF_SLIM_SHADOW")) c->wf.noSlimShadow = atoi(e) == 0;
+    if (const char* e = getenv("HRPT_WF_FUSED_PRIMARY")) c->wf.noFusedPrimary = atoi(e) == 0;
     if (const char* e = getenv("HRPT_WF_NODE_LOOP_MIN")) c->wf.nodeLoopMin = (uint32_t)atoi(e);
     *out = c;
     return HRPT_OK;
@@ -837,12 +838,12 @@ int hrpt_get_stats(HrptContext* c, HrptStats* out)
     DeviceCounters total{};
     for (int i = 0; i < kCounterShards; ++i) {
         total.closestRays += h[i].closestRays; total.shadowRays += h[i].shadowRays; total.paths += h[i].paths; total.neeEntries += h[i].neeEntries;
-        total.neeSamples += h[i].neeSamples; total.radianceShade += h[i].radianceShade; total.radianceShadow += h[i].radianceShadow;
+        total.neeSamples += h[i].neeSamples; total.radianceShade += h[i].radianceShade; total.radianceShadow += h[i].radianceShadow; total.skipped16 += h[i].skipped16;
     }
     out->closestRays = total.closestRays; out->shadowRays = total.shadowRays; out->paths = total.paths;
     out->neeEntries = total.neeEntries; out->neeSamples = total.neeSamples;
     out->megakernelFallbacks = c->megakernelFallbacks; out->queuePoolBytes = c->wf.poolBytes;
-    if (total.neeEntries || c->wf.raygenBytes) {     // the wavefront pipeline ran since the last reset
+    if (total.neeEntries || c->wf.raygenBytes || c->wf.resolveBytes) {     // the wavefront pipeline ran since the last reset
         wavefront_queue_bytes(c->wf, total, out->traceQueueBytes, out->shadeQueueBytes, out->shadowQueueBytes);
         out->raygenQueueBytes = c->wf.raygenBytes; out->resolveQueueBytes = c->wf.resolveBytes;
     }

@@ -19,7 +19,7 @@ struct DeviceCounters {         // 64 B; summed over the shards by hrpt_get_stat
     unsigned long long neeSamples;        // 4: light-sample records wf_shadow read
     unsigned long long radianceShade;     // 5: sampleRadiance read-modify-writes of wf_shade (emissive / sky terms)
     unsigned long long radianceShadow;    // 6: sampleRadiance read-modify-writes of wf_shadow (NEE terms)
-    unsigned long long pad;
+    unsigned long long skipped16;         // 7: 16-byte path-record reads wf_shadow's slim mode did not make at bounce 0 of a batch without raygen pass
 };
 
 struct TileRect {

@@ -43,7 +43,7 @@ struct WavefrontState {
     // queue-byte accounting (HrptStats::*QueueBytes): what the host knows per render is summed here, the rest follows from the device
     // counters and the record layout of the last render
     uint64_t raygenBytes = 0, resolveBytes = 0;
-    struct Layout { uint32_t pathRecordBytes = 48, maxLights = 1; int shadowMode = 0; } layout;
+    struct Layout { uint32_t pathRecordBytes = 48, maxLights = 1; int shadowMode = 0; bool fusedPrimary = false; } layout;
     // tuning knobs (0 = default)
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
@@ -60,6 +60,7 @@ struct WavefrontState {
     uint32_t bvhWidth = 0;             // 2 or 4: node width the trace kernels traverse; 0 = default
     bool forceGeneralShade = false;
     uint32_t nodeLoopMin = ~0u;        // HRPT_WF_NODE_LOOP_MIN: the descent loops end when fewer lanes than this are at inner nodes (~0 = automatic, 0 = never)
+    bool noFusedPrimary = false;       // HRPT_WF_FUSED_PRIMARY=0: SIMPLE scenes keep the wf_raygen pass (A/B knob)
     bool noSlimShadow = false;         // HRPT_WF_SLIM_SHADOW=0: the SIMPLE shade variant writes full 96-byte shadow-queue entries (A/B knob)
     int shadeSort = -1;                // HRPT_WF_SHADE_SORT = 0 / 1: general wf_shade variants shade in queue order / grouped by shading class (-1: automatic)
     int shadowPath = 0;                // scenes with non-opaque geometry: 0 = automatic, 1 = wf_shadow traverses itself (buffered query), 2 = any-hit pass + resolve

@@ -76,6 +76,10 @@ struct WfArgs {
     uint32_t shadowParity;     // ... and the path queue those slots index (the input queue of the bounce's wf_shade)
     uint32_t nodeLoopMin;      // wf_extend leaves its node-descent loop once fewer lanes than this are still at inner nodes (0: never)
     uint32_t sortShade;        // wf_shade (general variants) shades the entries of a segment grouped by shading class
+    const struct PrimaryArgs* primaryArgs;     // device copy (queue pool), valid when `primary`
+    uint32_t primary;          // this launch works on bounce 0 of a batch whose primary rays are NOT in the path queue: slot == sample index, every
+                               // wf_extend<PRIMARY> derives the ray of a slot from PrimaryArgs and leaves {direction, RNG seed} in rayD; origin = camera, throughput (1,1,1)
+                               // (no wf_raygen launch; SIMPLE scenes)
     int32_t* spill[2];         // per-lane stack overflow columns of wf_extend / wf_shadow (they run concurrently), element k of thread g at [k * threads + g]
     DeviceCounters* counters;
 };
@@ -83,6 +87,8 @@ struct WfArgs {
 enum : uint32_t { kVisNoRay = 0, kVisBlocked = 1, kVisClear = 2, kVisCandidates = 3 };   // shVis codes
 
 struct JitterTable { float2 j[kMaxSppPerBatch]; };
+// what the primary ray of a sample is computed from (PathTracer.hlsl:61-72, PathTracerRenderer.cpp:62-65); by value to the bounce-0 launches
+struct PrimaryArgs { float clipToWorld[16]; float cam[3]; float invW, invH; uint32_t accumIndex; float2 j[kMaxSppPerBatch]; };
 
 // Tile enumeration: row-major over the rectangle; with interleaved columns (stripeCount > 1) column-major, so that the consecutive tiles
 // of a segment stay neighbours in the image (8 pixels apart vertically instead of 8 * stripeCount horizontally: -3 % per rank at 8 ranks).
@@ -90,6 +96,37 @@ HRT_DEV void tile_position(const WfArgs& a, uint32_t tile, uint32_t& tcol, uint3
 {
     if (a.rect.stripeCount > 1u) { tcol = tile / a.tilesY; trow = tile - tcol * a.tilesY; }
     else { trow = tile / a.tilesX; tcol = tile - trow * a.tilesX; }
+}
+
+// Pixel and primary ray of sample `smp` of the batch (the body of wf_raygen; with a.primary the bounce-0 kernels call it instead of reading the
+// path queue). false: the sample's pixel lies outside the rectangle (tiles are padded to 8 x 8).
+HRT_DEV bool primary_ray(const WfArgs& a, const PrimaryArgs& pr, uint32_t smp, f3& o, f3& d, uint32_t& rng)
+{
+    const uint32_t k = smp / a.pixelsPadded, p = smp - k * a.pixelsPadded;
+    const uint32_t tile = p >> 6, within = p & 63u;
+    uint32_t tcol, trow; tile_position(a, tile, tcol, trow);
+    const uint32_t px = a.rect.column_x(tcol) + (within & 7u), py = a.rect.y0 + trow * 8u + (within >> 3);
+    if (!(px < a.rect.x1 && py < a.rect.y1)) return false;
+    // init_path (pt_path.h) with the jitter / RNG stream of accumulation index first + k (PathTracerRenderer.cpp:62,:65)
+    const float u = (((float)px + 0.5f) + pr.j[k].x) * pr.invW;
+    const float v = (((float)py + 0.5f) + pr.j[k].y) * pr.invH;
+    const float cx = u * 2.0f + -1.0f, cy = v * -2.0f + 1.0f;
+    const float* M = pr.clipToWorld;
+    const float ex = ((cx * M[0] + cy * M[4]) + 0.9f * M[8]) + 1.0f * M[12];
+    const float ey = ((cx * M[1] + cy * M[5]) + 0.9f * M[9]) + 1.0f * M[13];
+    const float ez = ((cx * M[2] + cy * M[6]) + 0.9f * M[10]) + 1.0f * M[14];
+    const float ew = ((cx * M[3] + cy * M[7]) + 0.9f * M[11]) + 1.0f * M[15];
+    const f3 end = mk3(ex / ew, ey / ew, ez / ew);
+    o = mk3(pr.cam[0], pr.cam[1], pr.cam[2]);
+    d = normalize(end - o);
+    rng = hrt_rng_seed(px, py, pr.accumIndex + k);
+    return true;
+}
+// entries of segment `seg` of the input path queue: counted by the producing kernel, or -- bounce 0 without a raygen pass -- every slot of the batch
+HRT_DEV uint32_t path_count(const WfArgs& a, uint32_t in, uint32_t seg)
+{
+    (void)in;
+    const uint32_t base = seg << a.segShift, left = a.numSamples - base, size = 1u << a.segShift; return left < size ? left : size;
 }
 
 // per-lane traversal stack in LDS: element (sp, lane-in-block) at base[sp * kBlock]
@@ -215,6 +252,15 @@ HRT_DEV void block_count_add_uniform(DeviceCounters* counters, const int (&field
     }
 }
 
+// PrimaryArgs into the queue pool (the kernels index its jitter table per lane: a by-value kernel argument would be copied to scratch for that)
+__global__ void wf_store_primary(PrimaryArgs pr, PrimaryArgs* dst)
+{
+    if (threadIdx.x < 16) dst->clipToWorld[threadIdx.x] = pr.clipToWorld[threadIdx.x];
+    if (threadIdx.x < 3) dst->cam[threadIdx.x] = pr.cam[threadIdx.x];
+    if (threadIdx.x == 0) { dst->invW = pr.invW; dst->invH = pr.invH; dst->accumIndex = pr.accumIndex; }
+    if (threadIdx.x < kMaxSppPerBatch) dst->j[threadIdx.x] = pr.j[threadIdx.x];
+}
+
 // ------------------------------------------------------------------ raygen
 __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerConstants cb, JitterTable jt)
 {
@@ -277,16 +323,20 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
 constexpr uint32_t kRefillMinDefault = 12;
+constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)
 
 // ANYHIT: the same persistent loop over the shadow-ray queue (sqO / sqD / sqId, sqCnt rays per segment): the first hit on an opaque
 // triangle ends the ray (kVisBlocked); otherwise the ray is clear or, if it crossed non-opaque triangles, left to wf_shadow's candidate
 // pass (kVisCandidates). Shadow rays get the lane refill closest-hit rays have: 3.8 -> 8 Grays/s on the glass config.
 // TL: the two-level structure of instanced scenes (pt_device.h "two-level traversal"): tree in global memory, closest hits only, every
 // instance opaque; the hit's instance goes to its own stream (hitInst) next to the hit record.
-template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, bool TL = false>
+// PRIMARY: bounce 0 of a batch without a raygen pass (WfArgs::primary): the refill derives the ray from the sample index. A separate instantiation:
+// as a run-time branch the extra live state cost the kernel 6 VGPRs and 3 % on EVERY bounce.
+template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, bool TL = false, bool PRIMARY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 : 5))) void wf_extend(WfArgs a, uint32_t parity)
 {
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
+    static_assert(!PRIMARY || !ANYHIT, "primary rays are closest-hit rays");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = ANYHIT ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
@@ -313,7 +363,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
         auto open_segment = [&]() {                             // first non-empty segment at or after `seg`
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = uniform(segCount[seg]);
+                cnt = uniform(PRIMARY ? path_count(a, 0u, seg) : segCount[seg]);
                 if (cnt) { segBase = (seg << a.segShift) * slotsPerSample; haveSeg = true; break; }
             }
         };
@@ -335,12 +385,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
             if (active) HRT_PHASE(ANYHIT ? PH_ANY_ITER : PH_EXT_ITER);
             if (haveSeg && (nIdle >= a.refillMin || nIdle == 64u)) {
                 const uint32_t idx = next + prefix_rank(mIdle);
-                if (!active && idx < cnt) {
+                bool take = !active && idx < cnt;
+                if constexpr (PRIMARY) {                // bounce 0, rays from the sample index (false: padding pixel of an 8 x 8 tile)
+                    if (take) {
+                        slot = segBase + idx; take = primary_ray(a, *a.primaryArgs, slot, r.o, r.d, rng); r.tmin = 0.0f; r.tmax = 1e10f; rng0 = rng;
+                        if (take) rayD[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(rng));      // for wf_shade(0) / wf_shadow(0): direction + RNG seed
+                        else a.b.hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNoPathRecord));   // padding pixel of an 8 x 8 tile: wf_shade skips the slot
+                    }
+                }
+                if (take) {
                     HRT_PHASE(ANYHIT ? PH_ANY_REFILL : PH_EXT_REFILL);
-                    slot = segBase + idx;
-                    float4 o = rayO[slot], d = rayD[slot];
-                    r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = ANYHIT ? d.w : 1e10f;
-                    rng = __float_as_uint(d.w); rng0 = rng;
+                    if constexpr (!PRIMARY) {
+                        slot = segBase + idx;
+                        float4 o = rayO[slot], d = rayD[slot];
+                        r.o = mk3(o.x, o.y, o.z); r.d = mk3(d.x, d.y, d.z); r.tmin = o.w; r.tmax = ANYHIT ? d.w : 1e10f;
+                        rng = __float_as_uint(d.w); rng0 = rng;
+                    }
                     blocked = false; candOverflow = false; candCount = 0;
                     lower.have = false;
                     best.valid = false; tlim = r.tmax; sp = 0;
@@ -460,6 +520,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
         }
     }
     if (!ANYHIT) block_count_add(&a.counters->closestRays, 0, nRays);      // shadow rays are counted by wf_shadow
+    if (PRIMARY) { __syncthreads(); block_count_add(&a.counters->closestRays, 2, nRays); }      // ... and the paths wf_raygen would have counted
 }
 
 // ------------------------------------------------------------------ stand-alone ray queries (hrpt_trace_rays) through the same persistent loop
@@ -597,9 +658,10 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 // sample at all, which the compaction needs), and -- for the lanes that have one -- again from the saved RNG state, writing the samples
 // straight into the entry's slots instead of buffering them per lane (AccumulateDirectLighting loops over all m_LightCount lights,
 // CommonLighting.hlsli:877-908; the reference's UI does not bound them).
-template <int MAXL, bool SIMPLE>
+template <int MAXL, bool SIMPLE, bool PRIMARY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 1 ? 4 : 3, MAXL != 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
+    static_assert(!PRIMARY || SIMPLE, "no raygen pass: SIMPLE scenes only");
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     const uint32_t in = parity, out = parity ^ 1u;
@@ -662,7 +724,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
         auto open_segment = [&]() {        // first non-empty segment at or after `seg`; empty ones get their (zero) counts written here
             haveSeg = false; cnt = 0; next = 0; outCount = 0; shCount = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
-                cnt = uniform(a.b.pathCnt[in][seg]);
+                cnt = uniform(PRIMARY ? path_count(a, in, seg) : a.b.pathCnt[in][seg]);
                 if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
                 if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
             }
@@ -678,7 +740,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             if (endsA && takeA < 64u) {
                 uint32_t probe = seg + totalWaves;
                 for (; probe < a.numSegments; probe += totalWaves) {
-                    cntB = uniform(a.b.pathCnt[in][probe]);
+                    cntB = uniform(PRIMARY ? path_count(a, in, probe) : a.b.pathCnt[in][probe]);
                     if (cntB) break;
                     if (lane == 0) { a.b.pathCnt[out][probe] = 0; a.b.shadowCnt[probe] = 0; }
                 }
@@ -700,9 +762,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                 uint32_t slot = inA ? baseA + ((SORT && permuted) ? (uint32_t)permBase[permSel * segSize + nextA + lane] : nextA + lane)
                                     : baseB + ((SORT && permutedB) ? (uint32_t)permBase[(permSel ^ 1u) * segSize + (lane - takeA)] : lane - takeA);
                 slotIn = slot;
-                float4 o = a.b.rayO[in][slot], d = a.b.rayD[in][slot], t = a.b.thr[in][slot];
+                float4 o, d, t;
+                if constexpr (PRIMARY) {         // origin = camera, direction + seed as wf_extend<PRIMARY> left them, unit throughput, sample = slot
+                    const PrimaryArgs& pr = *a.primaryArgs;
+                    o = make_float4(pr.cam[0], pr.cam[1], pr.cam[2], 0.0f); d = a.b.rayD[in][slot];
+                    t = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(slot));
+                } else { o = a.b.rayO[in][slot]; d = a.b.rayD[in][slot]; t = a.b.thr[in][slot]; }
                 float4 ha = a.b.hit[slot]; uint32_t tri = __float_as_uint(ha.w);
-                if (tri != 0xFFFFFFFFu) tri &= 0x1FFFFFFFu;          // bits 29-31: shading class (wf_extend)
+                const bool noPath = PRIMARY && tri == kNoPathRecord;        // padding pixel (only bounce 0 without a raygen pass has such slots)
+                if (tri < kNoPathRecord) tri &= 0x1FFFFFFFu;          // bits 29-31: shading class (wf_extend)
                 ps.ray.o = mk3(o.x, o.y, o.z); ps.ray.d = mk3(d.x, d.y, d.z); ps.ray.tmin = o.w; ps.ray.tmax = 1e10f;
                 ps.rng = __float_as_uint(d.w);
                 ps.throughput = mk3(t.x, t.y, t.z); smp = __float_as_uint(t.w);
@@ -712,7 +780,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                     ps.sigmaA = mk3(m0.x, m0.y, m0.z); ps.interiorIOR = m0.w; ps.sigmaS = mk3(m1.x, m1.y, m1.z); ps.inVolume = m1.w != 0.0f;
                 } else { ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); ps.interiorIOR = 1.0f; ps.inVolume = false; }
                 bool addRadiance = false; f3 add = mk3(0.0f, 0.0f, 0.0f);
-                if (tri != 0xFFFFFFFFu) {
+                if (noPath) {
+                } else if (tri != 0xFFFFFFFFu) {
                     HRT_PHASE(PH_SHADE_HIT);
                     Hit h; h.valid = true; h.t = ha.x; h.u = ha.y; h.v = ha.z; h.tri = tri; h.prim = 0; h.inst = s.instances ? a.b.hitInst[slot] : 0u; h.opaque = 1;
                     f3 emissiveTerm = mk3(0.0f, 0.0f, 0.0f);
@@ -740,14 +809,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                     miss_sky(s, cb, ps, bounce);   // ps.radiance = throughput * sky
                     addRadiance = true; add = ps.radiance;
                 }
-                if (addRadiance) {
+                if constexpr (PRIMARY) {
+                    // first term of the sample (a padding slot gets a zero nobody reads): 0 + term, stored (no wf_raygen zeroed sampleRadiance; the addition keeps the sign of a -0 term as the
+                    // read-modify-write below would)
+                    a.b.radiance[smp] = addRadiance ? make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else if (addRadiance) {
                     // radiance_total = radiance_total + term, in path order (x + 0 == x, so zero terms are skipped)
                     float4 r = a.b.radiance[smp];
                     r.x = r.x + add.x; r.y = r.y + add.y; r.z = r.z + add.z;
                     a.b.radiance[smp] = r;
                 }
                 if (lastBounce) alive = false;
-                wantRadiance = addRadiance;
+                wantRadiance = addRadiance && !PRIMARY;
             }
             nRadiance += (unsigned int)__popcll(__ballot(wantRadiance));
             // ---- wave-local compaction of survivors into the out queue of their own segment
@@ -931,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
 
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
-    unsigned int nRays = 0, nSamples = 0, nRadiance = 0;
+    unsigned int nRays = 0, nSamples = 0, nRadiance = 0, nSkipped16 = 0;
     // one shadow-queue entry: every light sample of one path vertex
     auto process = [&](uint32_t e) {
                 HRT_PHASE(PH_SHADOW_ENTRY);
@@ -951,7 +1024,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
                     else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
                     ++nRays;
                     if (shadow != 0.0f) {
-                        const float4 th = a.b.thr[a.shadowParity][slot];
+                        const float4 th = a.primary ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(slot)) : a.b.thr[a.shadowParity][slot];
+                        if (a.primary) ++nSkipped16;
                         const HrptMaterialConstants& mat = s.materials[__float_as_uint(h1.w)];
                         // GetPBRAttributes without textures (RaytracingCommon.hlsli:252-296): constants, roughness clamped at 0.04
                         f3 dif, spec;
@@ -1065,6 +1139,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
     block_count_add(&a.counters->closestRays, 4, nSamples);
     __syncthreads();
     block_count_add(&a.counters->closestRays, 6, nRadiance);
+    if (SLIM && a.primary) { __syncthreads(); block_count_add(&a.counters->closestRays, 7, nSkipped16); }
 }
 
 // ------------------------------------------------------------------ resolve: fold the indices in order (:332-339)
@@ -1098,6 +1173,7 @@ struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel 
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
+    if constexpr (W == 4) if (a.primary && !anyHit) { hipLaunchKernelGGL((wf_extend<L, D, W, false, false, true>), g, dim3(kBlock), sh, st, a, parity); return; }
     if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
     else hipLaunchKernelGGL((wf_extend<L, D, W, false>), g, dim3(kBlock), sh, st, a, parity);
 }
@@ -1139,7 +1215,11 @@ template <int D> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st,
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit = false)
 {
     if (v.twoLevel) {       // closest hits only (wavefront_render keeps the any-hit pass off for two-level scenes)
-        if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
+        if (a.primary) {
+            if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
+            else if (v.depth <= 32) hipLaunchKernelGGL((wf_extend<false, 32, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
+            else hipLaunchKernelGGL((wf_extend<false, 64, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
+        } else if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
         else if (v.depth <= 32) hipLaunchKernelGGL((wf_extend<false, 32, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
         else hipLaunchKernelGGL((wf_extend<false, 64, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
         return;
@@ -1278,6 +1358,11 @@ void wavefront_queue_bytes(const WavefrontState& st, const DeviceCounters& c, ui
         shadow = c.neeEntries * (32 + 16) + c.radianceShadow * (16 + 32);
     }
     if (st.layout.shadowMode == kShadowResolve) shadow += c.neeEntries * 32 + c.neeSamples * 16 + c.shadowRays * 72 + c.neeEntries * st.layout.maxLights * 8;
+    if (st.layout.fusedPrimary) {      // bounce 0 reads no path records: wf_extend only writes hits, wf_shade reads them and stores the first radiance term
+        trace -= c.paths * 16;                               // no record read, {direction, seed} written
+        shade = shade - c.paths * (path - 16) + c.paths * 16;     // 16 of the 48 record bytes read; first radiance term stored
+        shadow -= c.skipped16 * 16;
+    }
 }
 
 namespace {
@@ -1338,6 +1423,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     }
     size_t oHit = carve(capacity * 16);
     const size_t oHitInst = scene.instances ? carve(capacity * 4) : 0;
+    const size_t oPrimary = carve(sizeof(PrimaryArgs));
     size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16), oSh2 = carve(capacity * 16), oSh3 = carve(capacity * 16), oSh4 = carve(capacity * 16);
     size_t oShL = carve(capacity * 16 * maxLights);
     size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
@@ -1363,6 +1449,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         a.b.rayO[p] = (float4*)(base + oRayO[p]); a.b.rayD[p] = (float4*)(base + oRayD[p]); a.b.thr[p] = (float4*)(base + oThr[p]);
         a.b.med0[p] = (float4*)(base + oMed0[p]); a.b.med1[p] = (float4*)(base + oMed1[p]); a.b.pathCnt[p] = (uint32_t*)(base + oCnt[p]);
     }
+    a.primaryArgs = (const PrimaryArgs*)(base + oPrimary);
     a.b.hit = (float4*)(base + oHit); a.b.hitInst = scene.instances ? (uint32_t*)(base + oHitInst) : nullptr;
     a.b.sh0 = (float4*)(base + oSh0); a.b.sh1 = (float4*)(base + oSh1); a.b.sh2 = (float4*)(base + oSh2); a.b.sh3 = (float4*)(base + oSh3);
     a.b.sh4 = (float4*)(base + oSh4); a.b.shL = (float4*)(base + oShL);
@@ -1480,14 +1567,32 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             jt.j[k].x = hrpt_halton(cb.m_AccumulationIndex + k + 1, 2) - 0.5f;
             jt.j[k].y = hrpt_halton(cb.m_AccumulationIndex + k + 1, 3) - 0.5f;
         }
+        // SIMPLE scenes: no raygen pass. wf_extend<PRIMARY> (the bounce-0 launch) derives the primary ray and the RNG seed of a slot (= sample index) from
+        // PrimaryArgs in its refill and leaves {direction, seed} in rayD for wf_shade<PRIMARY> / wf_shadow, which take the camera position as origin and
+        // (1, 1, 1) as throughput; wf_shade(0) stores the first radiance term instead of adding to a zeroed array; padding pixels of the 8 x 8 tiles get
+        // a kNoPathRecord hit record. 96 B per sample less queue traffic and one launch less: config 2 -3 % one frame at a time, -4 % two in flight
+        // (HRPT_WF_FUSED_PRIMARY=0 keeps wf_raygen). As run-time branches inside the ordinary kernels the same code cost every bounce 6 % (extend) and
+        // 16 % (shade): the extra live values; and regenerating the ray in wf_shade instead of reading 16 bytes gave the saving back in instructions.
+        const bool fusedPrimary = simpleScene && !manyLights && maxLights <= kMaxLights && vE.width == 4 && !traits.hasMedium && !traits.hasStochasticAlpha && !st.noFusedPrimary;
+        PrimaryArgs pr{};
+        if (fusedPrimary) {
+            for (int i = 0; i < 16; ++i) pr.clipToWorld[i] = cb.m_View.m_MatClipToWorldNoOffset[i];
+            for (int i = 0; i < 3; ++i) pr.cam[i] = cb.m_CameraPos[i];
+            pr.invW = cb.m_View.m_ViewportSizeInv[0]; pr.invH = cb.m_View.m_ViewportSizeInv[1]; pr.accumIndex = cb.m_AccumulationIndex;
+            for (uint32_t k = 0; k < spp; ++k) pr.j[k] = jt.j[k];
+        }
+        if (fusedPrimary) hipLaunchKernelGGL(wf_store_primary, dim3(1), dim3(64), 0, stream, pr, const_cast<PrimaryArgs*>(a.primaryArgs));
+        st.layout.fusedPrimary = fusedPrimary;
         const bool timedEnds = st.profile && st.eventsUsed + 4 <= 4096;
-        if (timedEnds) timing_mark(st, stream, 3, true);
-        hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
-        if (timedEnds) timing_mark(st, stream, 3, false);
+        if (!fusedPrimary) {
+            if (timedEnds) timing_mark(st, stream, 3, true);
+            hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
+            if (timedEnds) timing_mark(st, stream, 3, false);
+        }
         {   // raygen: sampleRadiance zeroed + one path record per pixel of the rectangle and index; resolve: sampleRadiance read, Accumulation
             // read (when resuming) and written, Output written
             const uint64_t w = (uint64_t)rect.columns() * 8u, px = (w < rect.x1 - rect.x0 ? w : (uint64_t)rect.x1 - rect.x0) * (rect.y1 - rect.y0);
-            st.raygenBytes += (uint64_t)a.numSamples * 16 + px * spp * st.layout.pathRecordBytes;
+            if (!fusedPrimary) st.raygenBytes += (uint64_t)a.numSamples * 16 + px * spp * st.layout.pathRecordBytes;
             st.resolveBytes += px * ((uint64_t)spp * 16 + 32 + (cb.m_AccumulationIndex > 0 ? 16 : 0));
         }
         const int maxBounces = (int)cb.m_MaxBounces;
@@ -1521,6 +1626,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             const uint32_t parity = (uint32_t)bounce & 1u;
             const bool timed = st.profile && st.eventsUsed + 8 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
+            a.primary = (fusedPrimary && bounce == 0) ? 1u : 0u;
             launch_extend(vE, dim3(grid), vE.ldsBytes, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
@@ -1528,6 +1634,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
             if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
+            else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
             else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
