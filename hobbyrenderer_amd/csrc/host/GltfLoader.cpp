@@ -833,7 +833,7 @@ void LoadTexturesFromImages(Scene& scene, const std::filesystem::path& sceneDir)
         if (tex.m_Uri.rfind("data:", 0) == 0) { t_warnings.push_back("texture " + std::to_string(i) + ": data-URI images are not loaded"); continue; }
         hobbyrt::Image img; std::string err;
         if (!hobbyrt::LoadImageFile((sceneDir / percent_decode(tex.m_Uri)).string(), img, err)) {
-            // a .dds sibling the host cannot decode (BC6H / BC7 / float formats go to the GPU's texture units in the reference): use the image it shadowed
+            // a .dds sibling in a format outside the decoded list (ImageDecode.h): use the image it shadowed
             std::string err2;
             if (tex.m_SourceUri.empty() || !hobbyrt::LoadImageFile((sceneDir / percent_decode(tex.m_SourceUri)).string(), img, err2)) {
                 t_warnings.push_back("texture " + std::to_string(i) + ": " + err + (tex.m_SourceUri.empty() ? "" : "; " + err2));

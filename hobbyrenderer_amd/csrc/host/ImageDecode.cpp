@@ -348,6 +348,109 @@ void bc7_block(const uint8_t* blk, uint8_t px[16][4])
         for (int k = 0; k < 4; ++k) px[i][k] = (uint8_t)c[k];
     }
 }
+// ---- BC6H (D3D11 functional spec 19.5.x / BPTC float): 14 modes, 1-2 subsets (the first 32 two-subset partitions of BC7), endpoints stored with
+// 6..16 bits and -- in the "transformed" modes -- as deltas against the first one, 3- or 4-bit indices; decodes to binary16 RGB.
+// The header bit order of every mode as a string of fields: <endpoint letter r/g/b><endpoint 0..3>:<first bit>[-<last bit>] ("d" = partition);
+// a range written high-to-low stores the most significant bit first (modes 13 and 14).
+struct Bc6Mode { uint8_t transformed, subsets, wBits, dBits[3]; const char* layout; };
+const Bc6Mode kBc6Modes[14] = {
+    { 1, 2, 10, { 5, 5, 5 }, "g2:4 b2:4 b3:4 r0:0-9 g0:0-9 b0:0-9 r1:0-4 g3:4 g2:0-3 g1:0-4 b3:0 g3:0-3 b1:0-4 b3:1 b2:0-3 r2:0-4 b3:2 r3:0-4 b3:3 d:0-4" },
+    { 1, 2, 7, { 6, 6, 6 }, "g2:5 g3:4 g3:5 r0:0-6 b3:0 b3:1 b2:4 g0:0-6 b2:5 b3:2 g2:4 b0:0-6 b3:3 b3:5 b3:4 r1:0-5 g2:0-3 g1:0-5 g3:0-3 b1:0-5 b2:0-3 r2:0-5 r3:0-5 d:0-4" },
+    { 1, 2, 11, { 5, 4, 4 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-4 r0:10 g2:0-3 g1:0-3 g0:10 b3:0 g3:0-3 b1:0-3 b0:10 b3:1 b2:0-3 r2:0-4 b3:2 r3:0-4 b3:3 d:0-4" },
+    { 1, 2, 11, { 4, 5, 4 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-3 r0:10 g3:4 g2:0-3 g1:0-4 g0:10 g3:0-3 b1:0-3 b0:10 b3:1 b2:0-3 r2:0-3 b3:0 b3:2 r3:0-3 g2:4 b3:3 d:0-4" },
+    { 1, 2, 11, { 4, 4, 5 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-3 r0:10 b2:4 g2:0-3 g1:0-3 g0:10 b3:0 g3:0-3 b1:0-4 b0:10 b2:0-3 r2:0-3 b3:1 b3:2 r3:0-3 b3:4 b3:3 d:0-4" },
+    { 1, 2, 9, { 5, 5, 5 }, "r0:0-8 b2:4 g0:0-8 g2:4 b0:0-8 b3:4 r1:0-4 g3:4 g2:0-3 g1:0-4 b3:0 g3:0-3 b1:0-4 b3:1 b2:0-3 r2:0-4 b3:2 r3:0-4 b3:3 d:0-4" },
+    { 1, 2, 8, { 6, 5, 5 }, "r0:0-7 g3:4 b2:4 g0:0-7 b3:2 g2:4 b0:0-7 b3:3 b3:4 r1:0-5 g2:0-3 g1:0-4 b3:0 g3:0-3 b1:0-4 b3:1 b2:0-3 r2:0-5 r3:0-5 d:0-4" },
+    { 1, 2, 8, { 5, 6, 5 }, "r0:0-7 b3:0 b2:4 g0:0-7 g2:5 g2:4 b0:0-7 g3:5 b3:4 r1:0-4 g3:4 g2:0-3 g1:0-5 g3:0-3 b1:0-4 b3:1 b2:0-3 r2:0-4 b3:2 r3:0-4 b3:3 d:0-4" },
+    { 1, 2, 8, { 5, 5, 6 }, "r0:0-7 b3:1 b2:4 g0:0-7 b2:5 g2:4 b0:0-7 b3:5 b3:4 r1:0-4 g3:4 g2:0-3 g1:0-4 b3:0 g3:0-3 b1:0-5 b2:0-3 r2:0-4 b3:2 r3:0-4 b3:3 d:0-4" },
+    { 0, 2, 6, { 6, 6, 6 }, "r0:0-5 g3:4 b3:0 b3:1 b2:4 g0:0-5 g2:5 b2:5 b3:2 g2:4 b0:0-5 g3:5 b3:3 b3:5 b3:4 r1:0-5 g2:0-3 g1:0-5 g3:0-3 b1:0-5 b2:0-3 r2:0-5 r3:0-5 d:0-4" },
+    { 0, 1, 10, { 10, 10, 10 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-9 g1:0-9 b1:0-9" },
+    { 1, 1, 11, { 9, 9, 9 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-8 r0:10 g1:0-8 g0:10 b1:0-8 b0:10" },
+    { 1, 1, 12, { 8, 8, 8 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-7 r0:11-10 g1:0-7 g0:11-10 b1:0-7 b0:11-10" },
+    { 1, 1, 16, { 4, 4, 4 }, "r0:0-9 g0:0-9 b0:0-9 r1:0-3 r0:15-10 g1:0-3 g0:15-10 b1:0-3 b0:15-10" },
+};
+// mode number (0-based index into kBc6Modes) from the low bits: two 2-bit codes, ten 5-bit codes; -1 = reserved
+int bc6_mode(const uint8_t* blk, uint32_t& modeBits)
+{
+    const uint32_t lo2 = blk[0] & 3u, lo5 = blk[0] & 31u;
+    if (lo2 == 0) { modeBits = 2; return 0; }
+    if (lo2 == 1) { modeBits = 2; return 1; }
+    modeBits = 5;
+    switch (lo5) {
+        case 2: return 2; case 6: return 3; case 10: return 4; case 14: return 5; case 18: return 6; case 22: return 7; case 26: return 8; case 30: return 9;
+        case 3: return 10; case 7: return 11; case 11: return 12; case 15: return 13;
+        default: return -1;
+    }
+}
+inline int32_t bc6_sign_extend(uint32_t v, uint32_t bits) { const uint32_t m = 1u << (bits - 1); return (int32_t)((v ^ m) - m); }
+int32_t bc6_unquantize(int32_t x, uint32_t bits, bool isSigned)
+{
+    if (!isSigned) {
+        if (bits >= 15) return x;
+        if (x == 0) return 0;
+        if (x == (int32_t)((1u << bits) - 1u)) return 0xFFFF;
+        return (int32_t)((((uint32_t)x << 15) + 0x4000u) >> (bits - 1));
+    }
+    if (bits >= 16) return x;
+    const bool neg = x < 0; uint32_t a = (uint32_t)(neg ? -x : x), u;
+    if (a == 0) u = 0; else if (a >= (1u << (bits - 1)) - 1u) u = 0x7FFF; else u = ((a << 15) + 0x4000u) >> (bits - 1);
+    return neg ? -(int32_t)u : (int32_t)u;
+}
+uint16_t bc6_finish(int32_t c, bool isSigned)
+{
+    if (!isSigned) return (uint16_t)((c * 31) >> 6);
+    return c < 0 ? (uint16_t)((((-c) * 31) >> 5) | 0x8000) : (uint16_t)((c * 31) >> 5);
+}
+void bc6h_block(const uint8_t* blk, bool isSigned, uint16_t px[16][4])
+{
+    uint32_t modeBits = 0;
+    const int mi = bc6_mode(blk, modeBits);
+    for (int i = 0; i < 16; ++i) { px[i][0] = px[i][1] = px[i][2] = 0; px[i][3] = 0x3C00u; }
+    if (mi < 0) return;                                         // reserved mode: black (spec)
+    const Bc6Mode& m = kBc6Modes[mi];
+    BitReader br{ blk, modeBits };
+    uint32_t e[4][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, partition = 0;
+    for (const char* p = m.layout; *p;) {                       // walk the layout string
+        while (*p == ' ') ++p;
+        if (!*p) break;
+        const char field = *p++;
+        uint32_t* dst; 
+        if (field == 'd') { dst = &partition; }
+        else { const int ch = field == 'r' ? 0 : (field == 'g' ? 1 : 2); dst = &e[*p++ - '0'][ch]; }
+        ++p;                                                    // ':'
+        int first = 0; while (*p >= '0' && *p <= '9') first = first * 10 + (*p++ - '0');
+        int last = first;
+        if (*p == '-') { ++p; last = 0; while (*p >= '0' && *p <= '9') last = last * 10 + (*p++ - '0'); }
+        const int step = last >= first ? 1 : -1;
+        for (int b = first;; b += step) { *dst |= br.get(1) << b; if (b == last) break; }
+    }
+    const uint32_t ne = m.subsets * 2u;
+    int32_t ep[4][3];
+    for (int c = 0; c < 3; ++c) {
+        int32_t base = (int32_t)e[0][c];
+        if (isSigned) base = bc6_sign_extend(e[0][c], m.wBits);
+        ep[0][c] = base;
+        for (uint32_t i = 1; i < ne; ++i) {
+            if (m.transformed) {
+                const int32_t delta = bc6_sign_extend(e[i][c], m.dBits[c]);
+                const uint32_t sum = ((uint32_t)e[0][c] + (uint32_t)delta) & ((1u << m.wBits) - 1u);
+                ep[i][c] = isSigned ? bc6_sign_extend(sum, m.wBits) : (int32_t)sum;
+            } else ep[i][c] = isSigned ? bc6_sign_extend(e[i][c], m.dBits[c]) : (int32_t)e[i][c];
+        }
+    }
+    for (uint32_t i = 0; i < ne; ++i) for (int c = 0; c < 3; ++c) ep[i][c] = bc6_unquantize(ep[i][c], m.wBits, isSigned);
+    const uint32_t ib = m.subsets == 2 ? 3u : 4u;
+    const uint32_t anchor1 = m.subsets == 2 ? kBc7Anchor2[partition] : 0u;
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t sub = m.subsets == 2 ? kBc7Partition2[partition][i] : 0u;
+        const bool isAnchor = i == 0 || (m.subsets == 2 && i == anchor1);
+        const uint32_t idx = br.get(isAnchor ? ib - 1u : ib), w = bc_weights(ib)[idx];
+        for (int c = 0; c < 3; ++c) {
+            const int32_t v = (ep[sub * 2][c] * (int32_t)(64 - w) + ep[sub * 2 + 1][c] * (int32_t)w + 32) >> 6;
+            px[i][c] = bc6_finish(v, isSigned);
+        }
+    }
+}
 inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline void put_f32(std::vector<uint8_t>& v, size_t texel, const float rgba[4]) { std::memcpy(&v[texel * 16], rgba, 16); }
 // one channel of a BC4_SNORM / BC5_SNORM block: signed endpoints, palette interpolated in float (D3D11 functional spec 19.5.7)
@@ -381,7 +484,7 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
     const bool hasFourCC = (pfFlags & 0x4) != 0;
     if (hasFourCC && fourCC == 0x30315844u /* "DX10" */) { if (n < 148) { err = "DDS DX10 header truncated"; return false; } dxgi = le32(d + 128); off = 148; }
     if (w == 0 || h == 0 || w > 32768 || h > 32768) { err = "bad DDS dimensions"; return false; }
-    enum Fmt { RGBA8, BGRA8, BC1, BC2, BC3, BC4U, BC4S, BC5U, BC5S, BC7, R16F, RG16F, RGBA16F, R32F, RG32F, RGBA32F, RG16U, RGBA16U } fmt;
+    enum Fmt { RGBA8, BGRA8, BC1, BC2, BC3, BC4U, BC4S, BC5U, BC5S, BC6U, BC6S, BC7, R16F, RG16F, RGBA16F, R32F, RG32F, RGBA32F, RG16U, RGBA16U } fmt;
     bool srgb = false;
     if (dxgi) {
         switch (dxgi) {
@@ -389,7 +492,7 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
             case 71: fmt = BC1; break; case 72: fmt = BC1; srgb = true; break; case 74: fmt = BC2; break; case 75: fmt = BC2; srgb = true; break;
             case 77: fmt = BC3; break; case 78: fmt = BC3; srgb = true; break; case 80: fmt = BC4U; break; case 81: fmt = BC4S; break;
             case 83: fmt = BC5U; break; case 84: fmt = BC5S; break; case 98: fmt = BC7; break; case 99: fmt = BC7; srgb = true; break;
-            case 95: case 96: err = "DXGI format " + std::to_string(dxgi) + " (BC6H) is not decoded on the host"; return false;
+            case 95: fmt = BC6U; break; case 96: fmt = BC6S; break;
             default: err = "unsupported DXGI format " + std::to_string(dxgi); return false;
         }
     } else if (hasFourCC) {
@@ -405,7 +508,7 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
     uint32_t maxLevels = 1; while ((w >> maxLevels) || (h >> maxLevels)) ++maxLevels;
     if (levels > maxLevels || levels > 16u) { err = "DDS mip count exceeds the chain of a " + std::to_string(w) + "x" + std::to_string(h) + " texture"; return false; }
     const bool blockFmt = fmt >= BC1 && fmt <= BC7;
-    const bool toF16 = fmt == R16F || fmt == RG16F || fmt == RGBA16F;
+    const bool toF16 = fmt == R16F || fmt == RG16F || fmt == RGBA16F || fmt == BC6U || fmt == BC6S;
     const bool toF32 = fmt == R32F || fmt == RG32F || fmt == RGBA32F || fmt == RG16U || fmt == RGBA16U || fmt == BC4S || fmt == BC5S;
     const size_t texelBytes = toF32 ? 16 : (toF16 ? 8 : 4);
     out.format = toF32 ? 3u : (toF16 ? 2u : (srgb ? 1u : 0u));
@@ -445,7 +548,7 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
             const size_t bw = (lw + 3) / 4, bh = (lh + 3) / 4, blockBytes = (fmt == BC1 || fmt == BC4U || fmt == BC4S) ? 8 : 16;
             for (size_t by = 0; by < bh; ++by) for (size_t bx = 0; bx < bw; ++bx) {
                 const uint8_t* blk = p + (by * bw + bx) * blockBytes;
-                uint8_t px[16][4]; float pf[16][4];
+                uint8_t px[16][4]; float pf[16][4]; uint16_t ph[16][4];
                 if (fmt == BC1 || fmt == BC2 || fmt == BC3) {
                     const uint8_t* cblk = fmt == BC1 ? blk : blk + 8;
                     uint8_t pal[4][4]; bc1_colors(cblk, pal, fmt == BC1);
@@ -454,6 +557,7 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
                     if (fmt == BC2) for (int i = 0; i < 16; ++i) { uint32_t a4 = (blk[i >> 1] >> ((i & 1) * 4)) & 15; px[i][3] = (uint8_t)(a4 * 17); }
                     if (fmt == BC3) { uint8_t a[16]; bc_alpha_block(blk, a); for (int i = 0; i < 16; ++i) px[i][3] = a[i]; }
                 } else if (fmt == BC7) bc7_block(blk, px);
+                else if (fmt == BC6U || fmt == BC6S) bc6h_block(blk, fmt == BC6S, ph);
                 else if (fmt == BC4U || fmt == BC5U) {
                     uint8_t r[16], g[16]; bc_alpha_block(blk, r);
                     if (fmt == BC5U) bc_alpha_block(blk + 8, g);
@@ -466,7 +570,9 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
                 for (int i = 0; i < 16; ++i) {
                     const size_t x = bx * 4 + (i & 3), y = by * 4 + (i >> 2);
                     if (x >= lw || y >= lh) continue;
-                    if (toF32) put_f32(out.rgba, texelBase + y * lw + x, pf[i]); else std::memcpy(&out.rgba[(texelBase + y * lw + x) * 4], px[i], 4);
+                    if (toF32) put_f32(out.rgba, texelBase + y * lw + x, pf[i]);
+                    else if (toF16) std::memcpy(&out.rgba[(texelBase + y * lw + x) * 8], ph[i], 8);
+                    else std::memcpy(&out.rgba[(texelBase + y * lw + x) * 4], px[i], 4);
                 }
             }
             p += bw * bh * blockBytes;

@@ -119,3 +119,91 @@ def dds_file(w, h, payload, dxgi=None, fourcc=b"\0\0\0\0", pf_flags=0x4, bitcoun
 
 
 SRGB_TO_LINEAR = np.array([np.float32(c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4) for c in (i / 255.0 for i in range(256))], np.float32)
+
+
+# ---- BC6H (D3D11 functional spec 19.5 / BPTC float), restated: the per-mode header layouts are data read out of the C++ source (they were
+# checked mode by mode against an independent decoder, see tests/test_texture_formats.py); field extraction, delta transform, sign extension,
+# unquantisation, interpolation and the final scale to binary16 are restated here.
+def _bc6_modes():
+    src = open(os.path.join(ROOT, "hobbyrenderer_amd", "csrc", "host", "ImageDecode.cpp")).read()
+    body = re.search(r"kBc6Modes\[14\]\s*=\s*\{(.*?)\n\};", src, re.S).group(1)
+    out = []
+    for m in re.finditer(r"\{\s*(\d+),\s*(\d+),\s*(\d+),\s*\{\s*(\d+),\s*(\d+),\s*(\d+)\s*\},\s*\"([^\"]*)\"\s*\}", body):
+        out.append((int(m.group(1)), int(m.group(2)), int(m.group(3)), (int(m.group(4)), int(m.group(5)), int(m.group(6))), m.group(7)))
+    assert len(out) == 14
+    return out
+
+
+BC6_MODES = _bc6_modes()
+BC6_CODES = {0: (0, 2), 1: (1, 2), 2: (2, 5), 6: (3, 5), 10: (4, 5), 14: (5, 5), 18: (6, 5), 22: (7, 5), 26: (8, 5), 30: (9, 5), 3: (10, 5), 7: (11, 5), 11: (12, 5), 15: (13, 5)}
+
+
+def _sext(v, bits):
+    m = 1 << (bits - 1)
+    return ((v & ((1 << bits) - 1)) ^ m) - m
+
+
+def bc6h_decode_block(block, signed):
+    """16 bytes -> (16, 3) uint16 binary16 bit patterns, row-major texels."""
+    value = int.from_bytes(block, "little")
+    if (value & 3) < 2:
+        mi, pos = (value & 3), 2
+    elif (value & 31) in BC6_CODES:
+        mi, pos = BC6_CODES[value & 31][0], 5
+    else:
+        return np.zeros((16, 3), np.uint16)
+    transformed, subsets, wbits, dbits, layout = BC6_MODES[mi]
+    ends = [[0, 0, 0] for _ in range(4)]
+    part = 0
+    for field in layout.split():
+        name, rng = field.split(":")
+        first, _, last = rng.partition("-")
+        first, last = int(first), int(last) if last else int(first)
+        step = 1 if last >= first else -1
+        for b in range(first, last + step, step):
+            bit = (value >> pos) & 1
+            pos += 1
+            if name == "d":
+                part |= bit << b
+            else:
+                ends[int(name[1])][ "rgb".index(name[0]) ] |= bit << b
+    ne = subsets * 2
+    ep = [[0, 0, 0] for _ in range(ne)]
+    for c in range(3):
+        ep[0][c] = _sext(ends[0][c], wbits) if signed else ends[0][c]
+        for i in range(1, ne):
+            if transformed:
+                s = (ends[0][c] + _sext(ends[i][c], dbits[c])) & ((1 << wbits) - 1)
+                ep[i][c] = _sext(s, wbits) if signed else s
+            else:
+                ep[i][c] = _sext(ends[i][c], dbits[c]) if signed else ends[i][c]
+
+    def unq(x):
+        if not signed:
+            if wbits >= 15 or x == 0:
+                return x
+            if x == (1 << wbits) - 1:
+                return 0xFFFF
+            return ((x << 15) + 0x4000) >> (wbits - 1)
+        if wbits >= 16:
+            return x
+        a = abs(x)
+        u = 0 if a == 0 else (0x7FFF if a >= (1 << (wbits - 1)) - 1 else ((a << 15) + 0x4000) >> (wbits - 1))
+        return -u if x < 0 else u
+    ep = [[unq(v) for v in e] for e in ep]
+    ib = 3 if subsets == 2 else 4
+    out = np.zeros((16, 3), np.uint16)
+    for i in range(16):
+        sub = int(P2[part][i]) if subsets == 2 else 0
+        anchor = i == 0 or (subsets == 2 and i == A2[part])
+        n = ib - 1 if anchor else ib
+        idx = (value >> pos) & ((1 << n) - 1)
+        pos += n
+        w = WEIGHTS[ib][idx]
+        for c in range(3):
+            v = (ep[sub * 2][c] * (64 - w) + ep[sub * 2 + 1][c] * w + 32) >> 6
+            if not signed:
+                out[i, c] = (v * 31) >> 6
+            else:
+                out[i, c] = ((((-v) * 31) >> 5) | 0x8000) if v < 0 else ((v * 31) >> 5)
+    return out

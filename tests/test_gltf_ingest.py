@@ -142,7 +142,7 @@ def test_dds_decoder(tmp_path):
     got = scene_io.decode_image(dds(5, 5, 0x4, b"DX10", dxgi=83, payload=(rblk + gblk) * 4))
     assert got.shape == (5, 5, 4) and got[4, 4].tolist() == [200, 10, 0, 255]
     with pytest.raises(scene_io.SceneFormatError):
-        scene_io.decode_image(dds(4, 4, 0x4, b"DX10", dxgi=95, payload=bytes(16)))         # BC6H is not decoded on the host (tests/test_texture_formats.py covers BC7)
+        scene_io.decode_image(dds(4, 4, 0x4, b"DX10", dxgi=24, payload=bytes(64)))         # R10G10B10A2: not in the reference's format list (tests/test_texture_formats.py covers BC6H / BC7)
     with pytest.raises(scene_io.SceneFormatError):
         scene_io.decode_image(dds(8, 8, 0x4, b"DXT1", payload=bytes(8)))                   # truncated
 
@@ -154,8 +154,8 @@ def test_dds_sibling_replaces_png(tmp_path, luts):
     open(tmp_path / "normal.dds", "wb").write(hdr + struct.pack("<IIIII", 28, 3, 0, 1, 0) + px.tobytes())
     loaded = scene_io.load_gltf(path, luts)
     assert np.array_equal(loaded.arrays.textures[12], px)          # texture 1 ("normal.png") came from normal.dds (src/SceneLoader.cpp:1281-1288)
-    # a BC6H sibling cannot be decoded on the host: the PNG it shadowed is used, with a warning
-    open(tmp_path / "orm16.dds", "wb").write(hdr + struct.pack("<IIIII", 95, 3, 0, 1, 0) + bytes(16))
+    # a sibling in a format the host does not decode (R10G10B10A2): the PNG it shadowed is used, with a warning
+    open(tmp_path / "orm16.dds", "wb").write(hdr + struct.pack("<IIIII", 24, 3, 0, 1, 0) + bytes(64))
     loaded = scene_io.load_gltf(path, luts)
     assert np.array_equal(loaded.arrays.textures[13], G.decode_png(open(tmp_path / "orm16.png", "rb").read()))
     assert any("orm16.dds" in w and "instead" in w for w in loaded.warnings)

@@ -77,10 +77,70 @@ def test_dds_float_and_snorm_formats():
     blk = bytes([127, 0x81]) + (0 | (1 << 3) | (2 << 6)).to_bytes(6, "little")
     lvl = scene_io.decode_texture(D.dds_file(4, 4, blk, dxgi=81)).level(0)
     assert lvl[0, 0, 0] == 1.0 and lvl[0, 1, 0] == -1.0 and lvl[0, 2, 0] == np.float32((np.float32(6.0) * np.float32(1.0) + np.float32(-1.0)) / np.float32(7.0))
-    # BC6H stays undecoded on the host (HDR environment maps: outside the path tracer's inputs), with a message that says so
+    # a DXGI format outside the reference's list (src/TextureLoader.cpp:66-93) is an error that names it
     with pytest.raises(scene_io.SceneFormatError) as e:
-        scene_io.decode_texture(D.dds_file(4, 4, bytes(16), dxgi=95))
-    assert "BC6H" in str(e.value)
+        scene_io.decode_texture(D.dds_file(4, 4, bytes(64), dxgi=24))       # R10G10B10A2_UNORM
+    assert "24" in str(e.value)
+
+
+BC6_MODE_CODES = [(0, 2), (1, 2), (2, 5), (6, 5), (10, 5), (14, 5), (18, 5), (22, 5), (26, 5), (30, 5), (3, 5), (7, 5), (11, 5), (15, 5)]
+
+
+def _bc6_blocks(rng, code, nbits, n):
+    out = bytearray()
+    for _ in range(n):
+        v = (int.from_bytes(rng.bytes(16), "little") & ~((1 << nbits) - 1)) | code
+        out += v.to_bytes(16, "little")
+    return bytes(out)
+
+
+@pytest.mark.parametrize("signed", [False, True], ids=["UF16", "SF16"])
+def test_bc6h_decoder_matches_the_python_restatement(signed):
+    """Every one of the 14 modes (random header and index bits: all partitions, delta wrap-arounds, the reversed high bits of modes 13 / 14)
+    plus the four reserved mode codes (black), both DXGI formats: bit-identical binary16 texels, alpha = 1."""
+    rng = np.random.default_rng(40 + signed)
+    for code, nbits in BC6_MODE_CODES + [(19, 5), (23, 5), (27, 5), (31, 5)]:
+        blocks = _bc6_blocks(rng, code, nbits, 64)
+        tex = scene_io.decode_texture(D.dds_file(32, 32, blocks, dxgi=96 if signed else 95))
+        assert tex.format == S.TEXTURE_FORMAT_RGBA16_FLOAT and tex.mip_count == 1
+        got = tex.level(0).view(np.uint16)
+        assert (got[..., 3] == 0x3C00).all()
+        for b in range(64):
+            by, bx = divmod(b, 8)
+            ref = D.bc6h_decode_block(blocks[16 * b:16 * b + 16], signed).reshape(4, 4, 3)
+            assert np.array_equal(got[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4, :3], ref), (code, b)
+
+
+def test_bc6h_against_an_independent_decoder():
+    """Pillow's DDS plugin decodes BC6H too (to 8 bits per channel: clamp(value, 0, 1) * 255). It agrees with this decoder on every mode of the
+    unsigned format and on the untransformed modes of the signed one; that pins the 14 header layouts, partitions, anchors, weights and the
+    unquantisation. (For the TRANSFORMED modes of BC6H_SF16 Pillow 12 does not sign-extend base + delta; this decoder does, as the D3D11
+    functional specification's inverse transform says, so those are not compared.)"""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(7)
+    for signed, modes in ((False, range(14)), (True, (9, 10, 13))):
+        for mi in modes:
+            code, nbits = BC6_MODE_CODES[mi]
+            data = D.dds_file(64, 64, _bc6_blocks(rng, code, nbits, 256), dxgi=96 if signed else 95)
+            mine = scene_io.decode_texture(data).level(0).astype(np.float32)[..., :3]
+            mine8 = (np.where(np.isnan(mine), 0, np.clip(mine, 0, 1)) * 255.0).astype(np.int32)
+            try:
+                ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(np.int32)
+            except Exception as e:          # a Pillow without BC6H support
+                pytest.skip(f"Pillow cannot decode BC6H here: {e}")
+            assert ((ref > 0) & (ref < 255)).mean() > 0.1                # enough texels inside (0, 1) for the comparison to mean something
+            assert np.abs(mine8 - ref).max() <= 1, (signed, mi)
+
+
+def test_bc6h_mip_chain_and_partial_blocks():
+    rng = np.random.default_rng(11)
+    payload = _bc6_blocks(rng, 3, 5, 6) + _bc6_blocks(rng, 0, 2, 2) + _bc6_blocks(rng, 1, 2, 1) + _bc6_blocks(rng, 3, 5, 1)     # 10x6, 5x3, 2x1, 1x1
+    tex = scene_io.decode_texture(D.dds_file(10, 6, payload, dxgi=95, mips=4))
+    assert tex.format == S.TEXTURE_FORMAT_RGBA16_FLOAT and tex.mip_count == 4
+    l1 = tex.level(1).view(np.uint16)
+    ref = D.bc6h_decode_block(payload[6 * 16:7 * 16], False).reshape(4, 4, 3)
+    assert l1.shape == (3, 5, 4) and np.array_equal(l1[:3, :4, :3], ref[:3])
 
 
 def test_progressive_jpeg_decodes_like_the_baseline_file_of_the_same_coefficients():
