@@ -390,7 +390,12 @@ def main():
             valu_doc, valu_src = _pmc_file("valu", args.config)
             at_baseline = world == 1 and (W, H, spp, bounces) == (1920, 1080, base_spp, base_bounces)
             # config 5's counters were collected at 8 of its 64 spp (per-launch figures do not depend on the spp count beyond the batch size)
-            traffic = (traffic_doc or {}).get(kernel, {}).get("hbm_bytes_per_launch") if at_baseline else None
+            traffic = None
+            if at_baseline and traffic_doc:
+                # launch-weighted over the instantiations of the class (the bounce-0 ones of a batch without raygen pass are listed as *_primary)
+                rows = [v for k, v in traffic_doc.items() if k in (kernel, kernel + "_primary") and v.get("hbm_bytes_per_launch") is not None]
+                n = sum(v.get("launches_sampled", 1) for v in rows)
+                traffic = sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in rows) / n if n else None
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel": kernel, "avg_launch_ms": avg_ms, "launches_per_step": launches, "queue_bytes_per_launch": per_launch_bytes,

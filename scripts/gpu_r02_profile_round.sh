@@ -20,6 +20,7 @@ for cfg in 2 4 5; do
   [ -f hobbyrenderer_amd/libhobbyrt_pt_phases.so ] && python3 scripts/phase_profile.py $cfg 2>&1 | grep -v amdgpu.ids > $OUT/phase_profile_config$cfg.txt
 done
 python3 scripts/ray_query_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/ray_query_bench.txt
+python3 scripts/two_level_bench.py 64 128 256 2>&1 | grep -v amdgpu.ids > $OUT/two_level_bench.txt
 for l in 2 3; do for n in 8 4 2; do LANES=$l python3 scripts/shard_host_overhead_probe.py $n 2>&1 | grep "N=" | tail -1 | sed "s/^/lanes=$l /"; done; done > $OUT/shard_probe.txt
 cut -c1-160 $OUT/rocprofv3_kernel_stats.csv | head -12
 python3 - <<'PY'

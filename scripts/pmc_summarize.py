@@ -12,16 +12,22 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(wf_shadow_rays|wf_[a-z]+|pt_megakernel)(<[^>]*>)?", row["Kernel_Name"])
+        m = re.search(r"(wf_shadow_rays|wf_store_primary|wf_[a-z]+|pt_megakernel)(<[^>]*>)?", row["Kernel_Name"])
         if not m:
             continue
         name = m.group(1)
-        if name == "wf_extend" and m.group(2) and m.group(2).rstrip(">").split(",")[-1].strip() in ("true", "1"):
+        targs = [a.strip() for a in m.group(2).strip("<>").split(",")] if m.group(2) else []
+        # wf_extend<LDS, DEPTH, W, ANYHIT, TL, PRIMARY>, wf_shade<MAXL, SIMPLE, PRIMARY>: the any-hit pass and the bounce-0 instantiations get their own rows
+        if name == "wf_extend" and len(targs) > 3 and targs[3] in ("true", "1"):
             name = "wf_extend_anyhit"
+        elif name == "wf_extend" and len(targs) > 5 and targs[5] in ("true", "1"):
+            name = "wf_extend_primary"
+        elif name == "wf_shade" and len(targs) > 2 and targs[2] in ("true", "1"):
+            name = "wf_shade_primary"
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for f in glob.glob(out + "/p1/**/*kernel_trace.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(wf_shadow_rays|wf_[a-z]+|pt_megakernel)", row["Kernel_Name"])
+        m = re.search(r"(wf_shadow_rays|wf_store_primary|wf_[a-z]+|pt_megakernel)", row["Kernel_Name"])
         if m:
             dur[m.group(1)].append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6)
 CUS, SIMDS = 256, 1024
