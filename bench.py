@@ -404,7 +404,11 @@ def main():
                                                         "correction; committed file, not measured in this run)") if traffic is not None else None,
                 "whole_step": {"queue_bytes": all_bytes / prof_steps, "kernel_ms": all_ms / prof_steps,
                                "queue_GBps": all_bytes / (all_ms * 1e-3) / 1e9, "frac": all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "bytes_per_sample": all_bytes / prof_steps / (W * H * spp / world)},
+                               "bytes_per_sample": all_bytes / prof_steps / (W * H * spp / world),
+                               # the same bytes against the TIMED step (frames in flight overlap: the rate at which the design streams its queues
+                               # through HBM while `value` is measured), this rank's share
+                               "timed_region_GBps": all_bytes / prof_steps / (elapsed / args.steps) / 1e9,
+                               "timed_region_frac": all_bytes / prof_steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
                 "kernels": kernel_times,
                 "valu": ({**valu_doc.get(kernel, {}), "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"}
                          if (valu_doc and at_baseline) else None),

@@ -186,6 +186,33 @@ def test_wavefront_equals_megakernel_full_size_configs_4_and_5(ctx, luts, config
     assert (wf[..., 3] == 2).all() and np.isfinite(wf).all()
 
 
+def test_config5_at_its_own_64_spp_and_12_bounces(ctx, luts):
+    """BASELINE config 5 at ITS parameters (1920x1080, 64 spp in one call = one batch of 133 M samples through a 42 GB queue pool, 12 bounces,
+    three lights: 1.3 G rays): wavefront == megakernel bit for bit with equal ray counters, and a 16-row band against the oracle at all 64
+    accumulation indices."""
+    sc, view, pos, cfg = scenes.config_glass(luts, 1920, 1080)
+    assert (cfg["spp"], cfg["max_bounces"]) == (64, 12)
+    ctx.upload_scene(sc); ctx.resize(1920, 1080)
+    cb = scenes.fill_constants(view, pos, sc, 0, 12)
+    ctx.reset_stats()
+    ctx.render(cb, accum_count=64, flags=S.FRAME_DEFAULT)
+    wf = ctx.read_accumulation(); st_wf = ctx.stats()
+    assert st_wf.megakernelFallbacks == 0 and st_wf.closestRays + st_wf.shadowRays > 1_200_000_000
+    assert (wf[..., 3] == 64).all() and np.isfinite(wf).all()
+    ctx.resize(1920, 1080)
+    ctx.reset_stats()
+    ctx.render(cb, accum_count=64, flags=S.FRAME_MEGAKERNEL)
+    mk = ctx.read_accumulation(); st_mk = ctx.stats()
+    assert (st_mk.closestRays, st_mk.shadowRays, st_mk.paths) == (st_wf.closestRays, st_wf.shadowRays, st_wf.paths)
+    assert np.array_equal(mk.view(np.uint32), wf.view(np.uint32))
+    from oracle.binding import Oracle
+    o = Oracle(sc)
+    band = (0, 600, 1920, 616)
+    oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, sc, i, 12), 1920, 1080, 64, tile=band)
+    o.close()
+    assert np.array_equal(wf[600:616].view(np.uint32), oacc[600:616].view(np.uint32))
+
+
 def test_progressive_resume_and_tiles(ctx, luts):
     """first_accum_index + existing accumulation (resume) and tile rectangles give the same image as one call."""
     sc, view, pos, cfg = scenes.config_cornell(luts, 128, 72)
