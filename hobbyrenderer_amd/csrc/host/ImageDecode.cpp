@@ -46,7 +46,7 @@ const uint16_t kDistBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97
 const uint8_t kDistExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
 }
 
-bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::string& err)
+bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::string& err, size_t maxOut)
 {
     out.clear();
     if (n < 6) { err = "zlib stream too short"; return false; }
@@ -59,6 +59,7 @@ bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::stri
             b.align();
             uint32_t len = b.get(16), nlen = b.get(16);
             if ((len ^ 0xFFFFu) != nlen) { err = "stored block length mismatch"; return false; }
+            if (out.size() + len > maxOut) { err = "more data than the container announced"; return false; }
             for (uint32_t i = 0; i < len; ++i) out.push_back((uint8_t)b.get(8));
         } else if (type == 1 || type == 2) {
             Huff lit, dist; uint8_t lengths[320];
@@ -96,7 +97,7 @@ bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::stri
             for (;;) {
                 int sym = lit.decode(b);
                 if (sym < 0 || b.overrun) { err = "bad literal/length code or truncated stream"; return false; }
-                if (sym < 256) out.push_back((uint8_t)sym);
+                if (sym < 256) { if (out.size() >= maxOut) { err = "more data than the container announced"; return false; } out.push_back((uint8_t)sym); }
                 else if (sym == 256) break;
                 else {
                     sym -= 257;
@@ -107,6 +108,7 @@ bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::stri
                     uint32_t d = kDistBase[ds] + b.get(kDistExtra[ds]);
                     if (d > out.size()) { err = "distance beyond the window"; return false; }
                     size_t from = out.size() - d;
+                    if (out.size() + len > maxOut) { err = "more data than the container announced"; return false; }
                     for (uint32_t k = 0; k < len; ++k) out.push_back(out[from + k]);
                 }
             }
@@ -175,10 +177,16 @@ bool DecodePNG(const uint8_t* data, size_t n, Image& out, std::string& err)
                    ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
     if (!depthOk) { err = "bad PNG bit depth for the colour type"; return false; }
     if (ctype == 3 && (palette.empty() || palette.size() % 3)) { err = "palette PNG without PLTE"; return false; }
-    std::vector<uint8_t> raw;
-    if (!Inflate(idat.data(), idat.size(), raw, err)) { err = "PNG IDAT: " + err; return false; }
-
     const size_t bitsPerPixel = (size_t)channels * depth, bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;
+    // The header bounds the size of the filtered image data ((row bytes + 1 filter byte) per row; the seven Adam7 passes add at most one byte of
+    // rounding and one filter byte per pass row): the stream may not inflate past it (a few KB of IDAT can otherwise ask for gigabytes), and
+    // nothing of the image's size is allocated before the data turned out to be there.
+    const size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
+    const size_t maxRaw = (rowBytes + 1) * h + (interlace ? 2 * ((size_t)h + 7) * 7 : 0);
+    std::vector<uint8_t> raw;
+    if (!Inflate(idat.data(), idat.size(), raw, err, maxRaw)) { err = "PNG IDAT: " + err; return false; }
+    if (raw.size() < rowBytes * (size_t)h / (interlace ? 2 : 1)) { err = "PNG image data too short"; return false; }
+
     // samples[y][x][c] as 16-bit values in file precision
     std::vector<uint16_t> samples((size_t)w * h * channels);
     auto unpack = [&](const uint8_t* rows, size_t pw, size_t ph, size_t x0, size_t y0, size_t dx, size_t dy) {

@@ -18,7 +18,7 @@ namespace hobbyrt {
 // 3 RGBA32_FLOAT), all mip levels of the file, level 0 first, tightly packed in `rgba`.
 struct Image { uint32_t width = 0, height = 0; std::vector<uint8_t> rgba; uint32_t format = 0, mipCount = 1; };
 
-bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::string& err);   // zlib stream (RFC 1950/1951)
+bool Inflate(const uint8_t* data, size_t n, std::vector<uint8_t>& out, std::string& err, size_t maxOut = (size_t)-1);   // zlib stream (RFC 1950/1951)
 bool DecodePNG(const uint8_t* data, size_t n, Image& out, std::string& err);
 bool DecodeDDS(const uint8_t* data, size_t n, Image& out, std::string& err);
 bool Bc7TablesConsistent();     // self-check of the BC7 partition / anchor tables (every anchor lies in its own subset)

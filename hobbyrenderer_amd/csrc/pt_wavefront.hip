@@ -1408,39 +1408,43 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     }
     if (maxSamples * maxLights > 0xFFFFFFFFull) maxSamples = 0xFFFFFFFFull / maxLights;      // (entry, light) slot ids are 32-bit
     while (sppPerBatch > 1 && pixelsPadded * sppPerBatch > maxSamples) --sppPerBatch;
-    const uint64_t capacity = ((pixelsPadded * sppPerBatch + kMaxSegment - 1) / kMaxSegment) * kMaxSegment;
-    if (capacity >= (1ull << 31)) { error = "tile too large for one batch"; return hipErrorInvalidValue; }
-    const uint32_t segs = (uint32_t)(capacity / 64);   // counter arrays sized for the smallest segment
-
-    // ---- pool layout
+    // ---- pool layout (again with half the accumulation indices per batch when the device refuses the allocation)
+    uint64_t capacity = 0; uint32_t segs = 0;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oRayO[2], oRayD[2], oThr[2], oMed0[2] = { 0, 0 }, oMed1[2] = { 0, 0 }, oCnt[2];
+    size_t oHit = 0, oHitInst = 0, oPrimary = 0, oSh0 = 0, oSh1 = 0, oSh2 = 0, oSh3 = 0, oSh4 = 0, oShL = 0, oShCnt = 0, oRad = 0;
+    size_t oSqO = 0, oSqD = 0, oSqId = 0, oSqCnt = 0, oShVis = 0, oSqCand = 0;
+    for (;;) {
+    capacity = ((pixelsPadded * sppPerBatch + kMaxSegment - 1) / kMaxSegment) * kMaxSegment;
+    if (capacity >= (1ull << 31)) { error = "tile too large for one batch"; return hipErrorInvalidValue; }
+    segs = (uint32_t)(capacity / 64);   // counter arrays sized for the smallest segment
+    off = 0;
     for (int p = 0; p < 2; ++p) {
         oRayO[p] = carve(capacity * 16); oRayD[p] = carve(capacity * 16); oThr[p] = carve(capacity * 16);
         if (traits.hasMedium) { oMed0[p] = carve(capacity * 16); oMed1[p] = carve(capacity * 16); }
         oCnt[p] = carve((size_t)segs * 4);
     }
-    size_t oHit = carve(capacity * 16);
-    const size_t oHitInst = scene.instances ? carve(capacity * 4) : 0;
-    const size_t oPrimary = carve(sizeof(PrimaryArgs));
-    size_t oSh0 = carve(capacity * 16), oSh1 = carve(capacity * 16), oSh2 = carve(capacity * 16), oSh3 = carve(capacity * 16), oSh4 = carve(capacity * 16);
-    size_t oShL = carve(capacity * 16 * maxLights);
-    size_t oShCnt = carve((size_t)segs * 4), oRad = carve(capacity * 16);
-    size_t oSqO = 0, oSqD = 0, oSqId = 0, oSqCnt = 0, oShVis = 0, oSqCand = 0;
+    oHit = carve(capacity * 16);
+    oHitInst = scene.instances ? carve(capacity * 4) : 0;
+    oPrimary = carve(sizeof(PrimaryArgs));
+    oSh0 = carve(capacity * 16); oSh1 = carve(capacity * 16); oSh2 = carve(capacity * 16); oSh3 = carve(capacity * 16); oSh4 = carve(capacity * 16);
+    oShL = carve(capacity * 16 * maxLights);
+    oShCnt = carve((size_t)segs * 4); oRad = carve(capacity * 16);
     if (traits.hasNonOpaque || maxLights > 1) {     // (the mode is picked below; the arrays are small next to the path queues)
         oSqO = carve(capacity * 16 * maxLights); oSqD = carve(capacity * 16 * maxLights); oSqId = carve(capacity * 4 * maxLights);
         oSqCnt = carve((size_t)segs * 4); oShVis = carve(capacity * 4 * maxLights); oSqCand = carve(capacity * 8 * kShadowCandidates * maxLights);
     }
-    if (off > st.poolBytes) {
-        if (st.pool) { (void)hipStreamSynchronize(stream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
-        e = hipMalloc(&st.pool, off);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            error = "hipMalloc(queue pool, " + std::to_string(off >> 20) + " MiB for " + std::to_string(capacity) + " samples; render a smaller tile)";
-            return e;
-        }
-        st.poolBytes = off;
+    if (off <= st.poolBytes) break;
+    if (st.pool) { (void)hipStreamSynchronize(stream); if (st.auxStream) (void)hipStreamSynchronize(st.auxStream); (void)hipFree(st.pool); st.pool = nullptr; st.poolBytes = 0; }
+    e = hipMalloc(&st.pool, off);
+    if (e == hipSuccess) { st.poolBytes = off; break; }
+    (void)hipGetLastError();
+    if (sppPerBatch == 1 || st.maxSamplesPerBatch) {       // nothing left to halve (or the caller fixed the batch size)
+        error = "hipMalloc(queue pool, " + std::to_string(off >> 20) + " MiB for " + std::to_string(capacity) + " samples; render a smaller tile)";
+        return e;
+    }
+    sppPerBatch = (sppPerBatch + 1) / 2;
     }
     char* base = static_cast<char*>(st.pool);
     WfArgs a{};
