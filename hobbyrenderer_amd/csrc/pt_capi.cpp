@@ -752,7 +752,8 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
     if (!rays || !hits) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: null array");
     if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS | HRPT_RAYS_THREAD_PER_RAY))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
     if (count > (1ull << 31)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: too many rays in one call");
-    if (c->view.instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: not available on the two-level structure (hrpt_set_acceleration_structure)");
+    if (c->view.instances && ((flags & HRPT_RAYS_THREAD_PER_RAY) || !wavefront_trace_rays_supported(c->traits)))
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: the thread-per-ray kernel does not traverse the two-level structure (hrpt_set_acceleration_structure)");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool shadow = (flags & 0xFFu) == HRPT_RAYS_SHADOW;
     // the persistent refilling traversal kernel (pt_wavefront.hip wf_trace_rays); the thread-per-ray kernel stays as the fallback for trees

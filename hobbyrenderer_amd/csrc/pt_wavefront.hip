@@ -534,19 +534,21 @@ struct WfTraceArgs {
     int32_t* spill; uint32_t refillMin, nodeLoopMin;
 };
 constexpr uint32_t kTraceChunkShift = 8;
-template <bool LDS_BVH, int DEPTH, int W, bool SHADOW>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : 5))) void wf_trace_rays(WfTraceArgs a)
+template <bool LDS_BVH, int DEPTH, int W, bool SHADOW, bool TL = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : (TL ? 4 : 5)))) void wf_trace_rays(WfTraceArgs a)
 {
+    static_assert(!TL || (!LDS_BVH && W == 4), "two-level structure: global 4-wide trees (every instance opaque: a shadow ray ends at its first hit)");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = SHADOW ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kExtendLdsStack>::kRows * kBlock * 4) + threadIdx.x;
     if (DEPTH > kExtendLdsStack) { stack.spill = a.spill + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
-    typename GlobalBvhOf<W>::type gbvh = GlobalBvhOf<W>::make(a.scene);
+    typename GlobalBvhOf<(TL ? kTwoLevelTree : W)>::type gbvh = GlobalBvhOf<(TL ? kTwoLevelTree : W)>::make(a.scene);
     const SceneView& s = a.scene;
     const uint32_t wavesPerBlock = kBlock / 64;
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
+    TlCull tl; tl.inv = mk3(0.0f, 0.0f, 0.0f); tl.noi = tl.inv; tl.noiF = tl.inv; tl.inst = -1;      // TL only
     const uint64_t numChunks = (a.count + (1u << kTraceChunkShift) - 1) >> kTraceChunkShift;
     const bool emptyScene = s.nodeCount == 0 && s.rootLeaf == 0;
 
@@ -578,7 +580,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                 if (SHADOW) r = shadow_ray(o, d, q1.w);                                        // the query applies its own bias; tmax = distance to the light
                 else { r.o = o; r.d = d; r.tmin = q0.w; r.tmax = q1.w; }
                 rng = rr; blocked = false; candOverflow = false; candCount = 0; lower.have = false; best.valid = false; tlim = r.tmax; sp = 0;
-                sh = make_shear(r.d); inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv);
+                sh = make_shear(r.d);
+                if constexpr (TL) tl_world(tl, r); else { inv = traversal_rcp(r.d); noi = slab_origin_term(r.o, inv); }
                 cur = (emptyScene || !finite) ? kTraversalDone : (s.nodeCount == 0 ? s.rootLeaf : 0);
                 active = true;
             }
@@ -586,6 +589,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
         }
         if (__ballot(active) == 0ull) { if (haveChunk) continue; break; }
         if (active) {
+            if constexpr (TL) {
+                while (cur >= 0 && cur != kExitBlas) {
+                    cur = inner_step(gbvh, cur, tl.noi, tl.noiF, tl.inv, r.tmin, tlim, stack, sp);
+                    if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != kExitBlas)) < a.nodeLoopMin) break;
+                }
+                if (cur == kExitBlas || (cur < 0 && cur != kTraversalDone && tl.inst < 0)) cur = tl_switch(gbvh, cur, tl, r, stack, sp);
+                else if (cur < 0 && cur != kTraversalDone) {
+                    const GpuInstance& I = s.instances[tl.inst];
+                    const uint32_t enc = (uint32_t)(~cur), first = enc >> 2, count = (enc & 3u) + 1u, inst = (uint32_t)tl.inst;
+                    for (uint32_t i = 0; i < count; ++i) {
+                        float4 ta, tb, tc; gbvh.tri(first + i, ta, tb, tc);
+                        f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
+                        float t, u, v;
+                        const bool hitTri = tri_test(p0, p1, p2, r, sh, t, u, v);
+                        if (SHADOW) { if (hitTri) { blocked = true; break; } continue; }
+                        const uint32_t prim = __float_as_uint(tb.w);
+                        const bool take = hitTri && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see wf_extend<TL>
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+                        best.valid = best.valid || take; best.opaque = 1u;
+                        tlim = take ? t : tlim;
+                    }
+                    cur = blocked ? kTraversalDone : stack.pop(--sp);
+                }
+            } else {
             while (cur >= 0) {
                 if (LDS_BVH) cur = inner_step(lbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
                 else cur = inner_step(gbvh, cur, noi, inv, r.tmin, tlim, stack, sp);
@@ -614,6 +642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                     }
                 }
                 cur = (blocked || sp == 0) ? kTraversalDone : stack.pop(--sp);
+            }
             }
             if (cur == kTraversalDone) {
                 HrptRayHit out; out.t = 0.0f; out.u = 0.0f; out.v = 0.0f; out.instance = 0; out.primitive = 0; out.hit = 0; out.rng = rng; out.pad = 0;
@@ -1252,7 +1281,7 @@ template <bool L, bool SH> void launch_trace_rays_d(int depth, dim3 g, size_t ld
 
 
 
-bool wavefront_trace_rays_supported(const SceneTraits& traits) { return 3 * traits.bvh4MaxDepth + 2 <= kMaxStackNeed; }
+bool wavefront_trace_rays_supported(const SceneTraits& traits) { return (traits.twoLevelStackNeed ? traits.twoLevelStackNeed : 3 * traits.bvh4MaxDepth + 2) <= kMaxStackNeed; }
 
 hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, const SceneTraits& traits, const HrptRay* rays, HrptRayHit* hits, uint64_t count,
                                 bool shadow, hipStream_t stream, std::string& error)
@@ -1261,12 +1290,13 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     hipError_t e; int dev = 0; hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
-    const uint32_t need = 3 * traits.bvh4MaxDepth + 2;
+    const bool twoLevel = traits.twoLevelStackNeed != 0;
+    const uint32_t need = twoLevel ? traits.twoLevelStackNeed : 3 * traits.bvh4MaxDepth + 2;
     const int depth = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     const size_t candBytes = shadow ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     const size_t stackBytes = (size_t)(depth > kExtendLdsStack ? kExtendLdsStack : depth) * kBlock * 4;
     const size_t bvhBytes = (size_t)scene.node4Count * 128 + (size_t)scene.triCount * 48;
-    const bool lds = bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
+    const bool lds = !twoLevel && bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;
     const uint64_t chunks = (count + 255) / 256, blocksNeeded = (chunks + 3) / 4;
     uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = (uint32_t)blocksNeeded;
@@ -1286,6 +1316,11 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
         a.spill = static_cast<int32_t*>(st.traceSpill);
     }
     const size_t ldsBytes = stackBytes + (lds ? bvhBytes : 0);
+    if (twoLevel) {
+        const dim3 g(grid), b(kBlock); const size_t sl = ldsBytes;     // (no candidate columns: every instance is opaque)
+        if (shadow) { if (depth <= 16) hipLaunchKernelGGL((wf_trace_rays<false, 16, 4, true, true>), g, b, sl, stream, a); else if (depth <= 32) hipLaunchKernelGGL((wf_trace_rays<false, 32, 4, true, true>), g, b, sl, stream, a); else hipLaunchKernelGGL((wf_trace_rays<false, 64, 4, true, true>), g, b, sl, stream, a); }
+        else { if (depth <= 16) hipLaunchKernelGGL((wf_trace_rays<false, 16, 4, false, true>), g, b, sl, stream, a); else if (depth <= 32) hipLaunchKernelGGL((wf_trace_rays<false, 32, 4, false, true>), g, b, sl, stream, a); else hipLaunchKernelGGL((wf_trace_rays<false, 64, 4, false, true>), g, b, sl, stream, a); }
+    } else
     if (lds) { if (shadow) launch_trace_rays_d<true, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<true, false>(depth, dim3(grid), ldsBytes, stream, a); }
     else { if (shadow) launch_trace_rays_d<false, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<false, false>(depth, dim3(grid), ldsBytes, stream, a); }
     if ((e = hipGetLastError()) != hipSuccess) { error = "kernel launch"; return e; }

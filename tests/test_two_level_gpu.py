@@ -170,6 +170,44 @@ def test_two_level_matches_the_oracle(luts):
     assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
 
 
+def test_ray_queries_over_the_two_level_structure(luts):
+    """hrpt_trace_rays (closest hit and visibility) through wf_trace_rays<TL>: every ray as over the flat structure of the same scene -- random
+    rays from around the scene, rays aimed exactly at instance origins, a NaN direction."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    n = 24
+    sc = instanced_scene(luts, n, seed=13)
+    rng = np.random.default_rng(8)
+    m = 60000
+    rays = np.zeros(m, S.Ray)
+    rays["origin"] = (rng.random((m, 3)).astype(np.float32) - np.float32(0.5)) * np.float32([1.6 * n, 6.0, 1.6 * n]) + np.float32([0, 3.0, 0])
+    d = rng.normal(size=(m, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["direction"] = d
+    rays["tmin"] = np.where(rng.random(m) < 0.5, 0.0, 1e-3).astype(np.float32)
+    rays["tmax"] = np.where(rng.random(m) < 0.6, 1e10, rng.random(m) * 10).astype(np.float32)
+    t = sc.instances["m_World"][1:, 3, :3]
+    k = len(t)
+    rays["direction"][:k] = t - rays["origin"][:k]                # unnormalised directions at instance origins
+    rays["tmax"][:k] = 2.0
+    rays[k]["direction"] = (np.nan, 0, 1)
+    out = {}
+    for mode in (S.ACCEL_FLAT, S.ACCEL_TWO_LEVEL):
+        c = PathTracerContext(0)
+        try:
+            c.set_acceleration_structure(mode)
+            c.upload_scene(sc)
+            assert c.build_info().structure == mode
+            out[mode] = (c.trace_rays(rays), c.trace_rays(rays, shadow=True))
+        finally:
+            c.close()
+    (hf, vf), (ht, vt) = out[S.ACCEL_FLAT], out[S.ACCEL_TWO_LEVEL]
+    assert (hf["hit"] != 0).mean() > 0.3 and (vf["t"] == 0).mean() > 0.2
+    for f in ("hit", "instance", "primitive", "rng"):
+        assert np.array_equal(hf[f], ht[f]), f
+    for f in ("t", "u", "v"):
+        assert np.array_equal(hf[f].view(np.uint32), ht[f].view(np.uint32)), f
+    assert np.array_equal(vf["t"].view(np.uint32), vt["t"].view(np.uint32)) and np.array_equal(vf["hit"], vt["hit"])
+
+
 def test_scene_with_alpha_tested_instances_is_built_flat(luts):
     """Two-level needs every instance ForceOpaque; asking for it on a scene with MASK materials yields the flat tree (and correct frames)."""
     n = 6
@@ -199,7 +237,7 @@ def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
         rays["direction"] = (0, 0, 1)
         rays["tmax"] = 10
         with pytest.raises(HrptError):
-            c.trace_rays(rays)
+            c.trace_rays(rays, thread_per_ray=True)         # the persistent kernel does (test_ray_queries_over_the_two_level_structure)
         # a material change that makes an instance non-opaque rebuilds the structure flat
         m = sc.materials.copy()
         m["m_AlphaMode"][1] = S.ALPHA_MODE_BLEND
