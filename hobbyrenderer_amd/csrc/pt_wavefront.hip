@@ -323,6 +323,7 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
 constexpr uint32_t kRefillMinDefault = 12;
+constexpr uint32_t kShadeRing = 64;        // entries of wf_shade<SIMPLE>'s per-wave ring of parked specular-lobe paths
 constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)
 
 // ANYHIT: the same persistent loop over the shadow-ray queue (sqO / sqD / sqId, sqCnt rays per segment): the first hit on an opaque
@@ -687,8 +688,13 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 // sample at all, which the compaction needs), and -- for the lanes that have one -- again from the saved RNG state, writing the samples
 // straight into the entry's slots instead of buffering them per lane (AccumulateDirectLighting loops over all m_LightCount lights,
 // CommonLighting.hlsli:877-908; the reference's UI does not bound them).
+// Waves per SIMD: 4 for the SIMPLE variant (128 VGPRs with 13 spilled dwords; its ring of parked paths is 64 entries so that four blocks fit a
+// CU's LDS: -11 % shade time on config 2 against 3 waves with a 128-entry ring) and for the many-light variants; the general single-light variant
+// stays at 3: at 4 it is 7 % faster on config 4 and computes a WRONG sky radiance (tests/test_parity_gpu.py::test_random_material_subsets...
+// seeds 1 and 10: every miss pixel ~10 % off) -- the second time a forced register budget broke exactly this code in a general variant
+// (DESIGN.md section 4), so the setting is treated as a compiler hazard, not a tuning knob.
 template <int MAXL, bool SIMPLE, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 1 ? 4 : 3, MAXL != 1 ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MAXL != 1 || SIMPLE) ? 4 : 3, (MAXL != 1 || SIMPLE) ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     static_assert(!PRIMARY || SIMPLE, "no raygen pass: SIMPLE scenes only");
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
     // entries) and the wave runs the lobe for 64 of them at once (or for whatever is pending when a segment closes: their out-queue slots
     // belong to that segment). Per path the arithmetic is unchanged.
     extern __shared__ __attribute__((aligned(16))) char shadeSmem[];
-    constexpr uint32_t kRing = 128, kRingFields = 23;
+    constexpr uint32_t kRing = kShadeRing, kRingFields = 23;
     float* const ring = reinterpret_cast<float*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * kRing * kRingFields;
     uint32_t ringHead = 0, pending = 0;
     unsigned int nEntriesOut = 0, nRadiance = 0;      // wave-uniform statistics (HrptStats queue-byte accounting)
@@ -901,7 +907,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
             if (SIMPLE) {
                 // ---- park the lanes that picked the specular lobe
                 const unsigned long long md = __ballot(wantDefer);
-                if (wantDefer) {
+                const uint32_t nNew = (uint32_t)__popcll(md);
+                bool parked = false;
+                for (int round = 0; round < 2 && !parked; ++round) {
+                // (a ring of 64: when this iteration's lanes do not fit behind what is pending, the pending ones run first -- 58+ of 64 lanes, still dense)
+                parked = pending + nNew <= kRing;
+                if (parked && wantDefer) {
                     float* e = ring + ((ringHead + pending + prefix_rank(md)) & (kRing - 1u));
                     e[0 * kRing] = carry.N.x; e[1 * kRing] = carry.N.y; e[2 * kRing] = carry.N.z;
                     e[3 * kRing] = carry.V.x; e[4 * kRing] = carry.V.y; e[5 * kRing] = carry.V.z;
@@ -911,10 +922,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                     e[17 * kRing] = ps.throughput.x; e[18 * kRing] = ps.throughput.y; e[19 * kRing] = ps.throughput.z;
                     e[20 * kRing] = __uint_as_float(ps.rng); e[21 * kRing] = __uint_as_float(smp); e[22 * kRing] = inA ? 1.0f : 0.0f;
                 }
-                pending += (uint32_t)__popcll(md);
+                if (parked) pending += nNew;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 // ---- run the lobe for 64 parked paths at once; when segment A closes, for everything that is parked
-                while (pending >= 64u || (endsA && pending)) {
+                while (pending >= 64u || ((endsA || !parked) && pending)) {
                     const uint32_t n = pending < 64u ? pending : 64u;
                     bool alive2 = false, tagA = true; PathState q; uint32_t smp2 = 0;
                     if (lane < n) {
@@ -936,6 +947,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXL != 
                     outCount += (uint32_t)__popcll(m2A); outCountB += (uint32_t)__popcll(m2B);
                     ringHead = (ringHead + n) & (kRing - 1u); pending -= n;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
                 }
             }
             // ---- advance the cursor
@@ -1673,8 +1685,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
             if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
-            else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
-            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * 128 * 23 * 4, stream, a, cb, parity, bounce, last);
+            else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
+            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
             else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
