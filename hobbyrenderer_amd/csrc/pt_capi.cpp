@@ -210,15 +210,24 @@ static bool two_level_wanted(const HrptContext* c, const HrptSceneDesc& s, uint6
 }
 
 // instancesOnly: the mesh trees of c->twoLevel are kept (hrpt_update_instances)
+// kTwoLevelDoesNotFit: the scene cannot be held in this form (an instance with a singular world matrix -- a mesh flattened to a plane --, trees
+// too deep): the caller builds the flat structure instead, which has no such limits
+constexpr int kTwoLevelDoesNotFit = 1;
 static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v, bool instancesOnly)
 {
     std::string berr; int r;
     if (!instancesOnly) {
         delete c->twoLevel; c->twoLevel = new BuiltTwoLevel();
-        if (!build_scene_two_level(s, *c->twoLevel, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
-    } else if (!rebuild_two_level_instances(s, *c->twoLevel, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+        if (!build_scene_two_level(s, *c->twoLevel, berr)) {
+            if (berr.find("singular") != std::string::npos) return kTwoLevelDoesNotFit;
+            return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+        }
+    } else if (!rebuild_two_level_instances(s, *c->twoLevel, berr)) {
+        if (berr.find("singular") != std::string::npos) return kTwoLevelDoesNotFit;
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+    }
     const BuiltTwoLevel& b = *c->twoLevel;
-    if (two_level_stack_need(b) > 128u) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: two-level trees too deep for the traversal stacks");
+    if (two_level_stack_need(b) > 128u) return kTwoLevelDoesNotFit;
     if (!instancesOnly) {
         const HostTri* dt; const HostTriAttr* da; const HostTriTangent* dtg;
         if ((r = upload(c, b.tris.data(), b.tris.size(), &dt, &c->meshAllocations)) != HRPT_OK) return r;
@@ -260,8 +269,14 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
     free_acceleration(c, !firstBuild);
     if (keepMeshTrees || (firstBuild && two_level_wanted(c, s, sceneTris))) {
         r = build_two_level(c, s, v, keepMeshTrees);
-        c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return r;
+        if (r != kTwoLevelDoesNotFit) {
+            c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return r;
+        }
+        // flat after all: drop everything of the two-level form (a moved instance may have become singular: hrpt_update_instances ends up here too)
+        free_acceleration(c, false);
+        c->buildInfo.structure = HRPT_ACCEL_FLAT;
+        firstBuild = true;
     }
     v.instances = nullptr; v.instanceCount = 0; c->traits.twoLevelStackNeed = 0;
     if (sceneTris >= (1ull << 29)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: too many triangles for the flat structure (2^29; instanced scenes of opaque materials can use HRPT_ACCEL_TWO_LEVEL)");

@@ -334,7 +334,8 @@ int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
  * decided in world space on the world-space vertices the flat upload would produce. Two-level needs every instance material to be
  * OPAQUE (no any-hit candidates) and runs on the wavefront pipeline and the persistent ray-query kernel only (HRPT_FRAME_MEGAKERNEL,
  * HRPT_RAYS_THREAD_PER_RAY and hrpt_selftest_bvh answer HRPT_ERR_INVALID_ARGUMENT on such a scene; hrpt_trace_rays itself works); a
- * scene that does not qualify is built flat whatever was asked -- HrptBuildInfo::
+ * scene that does not qualify (a non-opaque instance material; an instance whose world matrix has no inverse, now or after a later
+ * hrpt_update_instances) is built flat whatever was asked -- HrptBuildInfo::
  * structure tells. AUTO: two-level when the scene qualifies, has at least 2 M world triangles and at least 8 instances per distinct mesh
  * on average (measured on MI355X, spheres / cylinders of ~400 triangles, 1920x1080, 8 spp, 4 bounces: 4 096 instances 19.7 ms flat vs
  * 19.0 ms two-level, 16 384: 27.7 vs 20.2 ms, 65 536: 44.0 vs 21.5 ms and 17.6 GB vs 30 MB -- the small trees stay in cache).

@@ -208,6 +208,46 @@ def test_ray_queries_over_the_two_level_structure(luts):
     assert np.array_equal(vf["t"].view(np.uint32), vt["t"].view(np.uint32)) and np.array_equal(vf["hit"], vt["hit"])
 
 
+def _small_scene(luts, worlds, tri_only=False, empty_mesh=False):
+    b = scenes.SceneBuilder()
+    quad_v, quad_i = scenes.generate_floor_quad()
+    floor = b.add_mesh(quad_v, quad_i)
+    mesh = b.add_mesh(quad_v, quad_i[:3]) if tri_only else b.add_mesh(*scenes.generate_default_cube())
+    mat = b.add_material(m_BaseColor=(0.7, 0.6, 0.5, 1))
+    if not tri_only:
+        b.add_instance(floor, mat, scenes._mat((8, 1, 8)))
+    if empty_mesh:
+        e = b.add_mesh(quad_v, quad_i[:0])
+        b.add_instance(e, mat, scenes._mat((1, 1, 1), None, (0.3, 0.5, 0.2)))
+    for w in worlds:
+        b.add_instance(mesh, mat, w)
+    return b.finalize(luts)
+
+
+def test_two_level_degenerate_shapes(luts):
+    """One instance of a one-triangle mesh (no instance tree, the mesh tree is a single leaf), an instance of a mesh without triangles, a
+    single cube: the same frames as the flat structure."""
+    view, pos = scenes.planar_view(96, 64, position=(0.2, 1.2, -4.0), pitch=0.2, aspect=1.5)
+    for sc in (_small_scene(luts, [scenes._mat((2, 1, 2), None, (0, 0.5, 0))], tri_only=True),
+               _small_scene(luts, [scenes._mat((1, 1, 1), _rot(np.random.default_rng(2)), (0, 0.8, 0))], empty_mesh=True),
+               _small_scene(luts, [scenes._mat((1, 2, 1), None, (0.5, 1.0, 0.5)), scenes._mat((0.5, 0.5, 0.5), None, (-1, 0.25, 0))])):
+        _same_frames(luts, sc, 96, 64, 2, 4, view, pos)
+
+
+def test_instance_flattened_to_a_plane_is_built_flat(luts):
+    """A world matrix without an inverse (scale 0 along one axis) cannot be traversed in object space: the flat structure is built instead --
+    at upload, and when hrpt_update_instances makes an instance of a two-level scene singular."""
+    view, pos = scenes.planar_view(96, 64, position=(0.2, 1.2, -4.0), pitch=0.2, aspect=1.5)
+    worlds = [scenes._mat((1, 2, 1), None, (0.5, 1.0, 0.5)), scenes._mat((0.8, 0.0, 0.8), None, (-1, 0.6, 0))]
+    sc = _small_scene(luts, worlds)
+    a_flat, n_flat, i_flat, _ = _render(luts, sc, S.ACCEL_FLAT, 96, 64, 2, 4, view, pos)
+    a_two, n_two, i_two, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, 96, 64, 2, 4, view, pos)
+    assert i_two.structure == S.ACCEL_FLAT and n_flat == n_two and np.array_equal(a_flat.view(np.uint32), a_two.view(np.uint32))
+    ok = _small_scene(luts, [worlds[0], scenes._mat((0.8, 0.5, 0.8), None, (-1, 0.6, 0))])
+    a_two, n_two, i_two, _ = _render(luts, ok, S.ACCEL_TWO_LEVEL, 96, 64, 2, 4, view, pos, update=sc.instances)
+    assert i_two.structure == S.ACCEL_FLAT and n_flat == n_two and np.array_equal(a_flat.view(np.uint32), a_two.view(np.uint32))
+
+
 def test_scene_with_alpha_tested_instances_is_built_flat(luts):
     """Two-level needs every instance ForceOpaque; asking for it on a scene with MASK materials yields the flat tree (and correct frames)."""
     n = 6
