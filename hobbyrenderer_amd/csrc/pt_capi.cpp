@@ -195,18 +195,20 @@ const char* hrpt_last_error(const HrptContext* c)
 // The acceleration structure + the records derived from instance transforms (Scene::BuildAccelerationStructures, src/Scene.cpp:67-214),
 // written into `v`. First build of a scene or a rebuild after hrpt_update_instances (the GPU builder then keeps its device-resident
 // geometry and buffers).
-// Two-level structure: qualifies when every instance is ForceOpaque (src/Scene.cpp:150-154: material alpha mode OPAQUE)
+// Two-level structure: asked for, or (AUTO) large and heavily instanced
 static bool two_level_wanted(const HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris)
 {
     int want = c->accelStructure;
     if (const char* e = getenv("HRPT_ACCEL_STRUCTURE")) { const int v = atoi(e); if (v >= HRPT_ACCEL_AUTO && v <= HRPT_ACCEL_TWO_LEVEL) want = v; }
     if (want == HRPT_ACCEL_FLAT || s.instanceCount == 0) return false;
-    for (uint32_t i = 0; i < s.instanceCount; ++i)
-        if (s.materials[s.instances[i].m_MaterialIndex].m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE) return false;
     if (want == HRPT_ACCEL_TWO_LEVEL) return true;
     std::vector<uint8_t> used(s.meshDataCount, 0); uint32_t distinct = 0;
     for (uint32_t i = 0; i < s.instanceCount; ++i) if (!used[s.instances[i].m_MeshDataIndex]) { used[s.instances[i].m_MeshDataIndex] = 1; ++distinct; }
-    return sceneTris >= (2ull << 20) && (uint64_t)s.instanceCount >= 8ull * distinct;
+    // scenes with non-opaque instances: the two-level shadow query re-traces per crossed candidate (2-3x the flat structure's buffered query on
+    // foliage / glass scenes), so AUTO only takes it where the flat structure's memory (~600 B per world triangle) becomes the problem
+    bool nonOpaque = false;
+    for (uint32_t i = 0; i < s.instanceCount && !nonOpaque; ++i) nonOpaque = s.materials[s.instances[i].m_MaterialIndex].m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE;
+    return sceneTris >= (nonOpaque ? (64ull << 20) : (2ull << 20)) && (uint64_t)s.instanceCount >= 8ull * distinct;
 }
 
 // instancesOnly: the mesh trees of c->twoLevel are kept (hrpt_update_instances)

@@ -478,10 +478,11 @@ HRT_DEV int32_t tl_switch(const GlobalBvhTl& bvh, int32_t cur, TlCull& c, const 
     return root;
 }
 
-// any_opaque over the two-level structure (every instance of such a scene is opaque: pt_capi.cpp only builds it then)
+// any_opaque over the two-level structure: true at the first triangle of a ForceOpaque instance; triangles of other instances are only noted
 template <class STACK>
-HRT_DEV bool any_hit_two_level(const GlobalBvhTl& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, uint32_t nodeLoopMin = 0)
+HRT_DEV bool any_hit_two_level(const GlobalBvhTl& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, STACK& stack, bool& sawNonOpaque, uint32_t nodeLoopMin = 0)
 {
+    sawNonOpaque = false;
     if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return false;
     RayShear sh = make_shear(r.d);
     TlCull c; tl_world(c, r);
@@ -503,12 +504,48 @@ HRT_DEV bool any_hit_two_level(const GlobalBvhTl& bvh, int32_t rootLeaf, uint32_
                 float4 ta, tb, tc; bvh.tri(first + i, ta, tb, tc);
                 f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
                 float t, u, v;
-                if (tri_test(p0, p1, p2, r, sh, t, u, v)) return true;
+                if (tri_test(p0, p1, p2, r, sh, t, u, v)) { if (I.flags & 1u) return true; sawNonOpaque = true; }
             }
             cur = stack.pop(--sp);          // never empty inside an instance: the exit marker is below
         }
     }
     return false;
+}
+// closest_any over the two-level structure: the closest triangle with key strictly above `lower` (candidate re-trace of the shadow query)
+template <class STACK>
+HRT_DEV Hit closest_two_level(const GlobalBvhTl& bvh, int32_t rootLeaf, uint32_t nodeCount, const Ray& r, HitKey lower, STACK& stack)
+{
+    Hit best; best.valid = false; best.t = r.tmax; best.inst = 0; best.prim = 0; best.u = 0; best.v = 0; best.opaque = 0; best.tri = 0;
+    if (!(r.d.x == r.d.x && r.d.y == r.d.y && r.d.z == r.d.z)) return best;
+    RayShear sh = make_shear(r.d);
+    TlCull c; tl_world(c, r);
+    int sp = 0; int32_t cur;
+    if (nodeCount == 0) { if (rootLeaf == 0) return best; cur = rootLeaf; }
+    else cur = 0;
+    float tlim = r.tmax;
+    for (;;) {
+        while (cur >= 0 && cur != kExitBlas) cur = inner_step(bvh, cur, c.noi, c.noiF, c.inv, r.tmin, tlim, stack, sp);
+        if (cur == kTraversalDone) break;
+        if (cur == kExitBlas || (cur < 0 && c.inst < 0)) { cur = tl_switch(bvh, cur, c, r, stack, sp); continue; }
+        const GpuInstance& I = bvh.instances[c.inst];
+        const uint32_t enc = (uint32_t)(~cur), first = enc >> 2, count = (enc & 3u) + 1u, inst = (uint32_t)c.inst;
+        for (uint32_t i = 0; i < count; ++i) {
+            float4 ta, tb, tc; bvh.tri(first + i, ta, tb, tc);
+            f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
+            float t, u, v;
+            const bool hitTri = tri_test(p0, p1, p2, r, sh, t, u, v);
+            const uint32_t prim = __float_as_uint(tb.w);
+            const bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+            const bool take = hitTri && ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));
+            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
+            best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
+            best.opaque = take ? (I.flags & 1u) : best.opaque;
+            best.valid = best.valid || take;
+            tlim = take ? t : tlim;
+        }
+        cur = stack.pop(--sp);
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------ triangle attributes

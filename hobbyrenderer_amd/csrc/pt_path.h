@@ -53,7 +53,7 @@ HRT_DEV void init_path(PathState& ps, const HrptPathTracerConstants& cb, uint32_
 // (one RNG draw, :181).
 HRT_DEV bool candidate_commits(const SceneView& s, const Hit& h, uint32_t& rng)
 {
-    TriVerts tv = load_tri_attr(s, h.tri);
+    TriVerts tv = load_hit_attr(s, h);
     const HrptMaterialConstants& mat = s.materials[tv.material];
     uint32_t alphaMode = mat.m_AlphaMode;
     if (alphaMode == HRPT_ALPHA_MODE_MASK || (alphaMode == HRPT_ALPHA_MODE_BLEND && !(mat.m_TransmissionFactor > 0.0f))) {
@@ -128,13 +128,92 @@ HRT_DEV Ray shadow_ray(f3 worldPos, f3 L, float maxDist)                        
     return ray;
 }
 
+// A crossed non-opaque triangle of a two-level scene (the per-candidate body above; material and transform come from the hit's instance, the
+// world-space vertices the mip-selecting alpha test wants from the instance's m_World).
+HRT_DEV bool shadow_candidate_two_level(const SceneView& s, const Ray& ray, const Hit& h, ShadowState& st)
+{
+    TriVerts tv = load_hit_attr(s, h);
+    const HrptMaterialConstants& mat = s.materials[tv.material];
+    f2 uv = interpolated_uv(tv, h.u, h.v);
+    if (mat.m_AlphaMode == HRPT_ALPHA_MODE_MASK) {
+        float alpha = mat.m_BaseColor[3];
+        if (mat.m_TextureFlags & HRPT_TEXFLAG_ALBEDO) {
+            const uint32_t ti = mat.m_AlbedoTextureIndex;
+            if (ti >= s.textureCount || !s.textures[ti].texels) alpha *= 0.0f;
+            else {
+                const GpuTexture& t = s.textures[ti];
+                if (t.mipCount <= 1u) alpha *= sample_texture_level(t.texels, t.format, (int)t.w, (int)t.h, 0u, mat.m_AlbedoSamplerIndex, uv).w;
+                else {      // GetShadowRayGradients (RaytracingCommon.hlsli:207-240) from the world-space triangle, as candidate_alpha_grad
+                    const float4* tp = reinterpret_cast<const float4*>(s.tris + h.tri);
+                    f3 p0, p1, p2; tl_world_triangle(s.instances[h.inst], tp[0], tp[1], tp[2], p0, p1, p2);
+                    const float w0 = (1.0f - h.u) - h.v;
+                    const f3 hitPos = (p0 * w0 + p1 * h.u) + p2 * h.v;
+                    const float dist = length(hitPos - ray.o);
+                    const float triangleArea = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+                    f2 uvRange;
+                    uvRange.x = hrt_max(tv.uv0.x, hrt_max(tv.uv1.x, tv.uv2.x)) - hrt_min(tv.uv0.x, hrt_min(tv.uv1.x, tv.uv2.x));
+                    uvRange.y = hrt_max(tv.uv0.y, hrt_max(tv.uv1.y, tv.uv2.y)) - hrt_min(tv.uv0.y, hrt_min(tv.uv1.y, tv.uv2.y));
+                    const float gradientScale = triangleArea / hrt_max(dist, 0.1f);
+                    f2 grad; grad.x = uvRange.x * gradientScale; grad.y = uvRange.y * gradientScale;
+                    alpha *= sample_texture_grad(t, mat.m_AlbedoSamplerIndex, uv, grad, grad).w;
+                }
+            }
+        }
+        return alpha >= mat.m_AlphaCutoff;
+    }
+    if (mat.m_AlphaMode != HRPT_ALPHA_MODE_BLEND) return true;
+    float alpha = candidate_alpha(s, mat, uv);
+    float opacity = hrt_saturate(alpha * (1.0f - mat.m_TransmissionFactor));
+    st.transmission *= (1.0f - opacity);
+    if (mat.m_TransmissionFactor > 0.0f && mat.m_IsThinSurface == 0) {
+        float w0 = (1.0f - h.u) - h.v;
+        f3 ln = (tv.n0 * w0 + tv.n1 * h.u) + tv.n2 * h.v;
+        f3 wn = normalize(transform_normal(ln, s.instShade[tv.inst]));
+        bool front = dot(wn, ray.d) < 0.0f;
+        if (front) { st.inVolume = true; st.inVolumeStartT = h.t; st.sigmaT = mk3(mat.m_SigmaA) + mk3(mat.m_SigmaS); }
+        else if (st.inVolume) {
+            float seg = hrt_max(0.0f, h.t - st.inVolumeStartT);
+            f3 tr = mk3(hrt_exp(-st.sigmaT.x * seg), hrt_exp(-st.sigmaT.y * seg), hrt_exp(-st.sigmaT.z * seg));
+            st.transmission *= dot(tr, mk3(0.2126f, 0.7152f, 0.0722f));
+            st.inVolume = false;
+        }
+    }
+    return st.transmission <= 1e-3f;
+}
+// CalculateRTShadow<true> over the two-level structure, re-trace form: an any-hit pass over the opaque instances, then -- only for a ray that
+// crossed triangles of non-opaque instances -- one closest-hit query per candidate, front to back (the visiting order of every other form).
+template <class STACK>
+HRT_DEV float shadow_retrace_two_level(const SceneView& s, const GlobalBvhTl& bvh, const Ray& ray, STACK& stack)
+{
+    ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
+    HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
+    for (;;) {
+        Hit h = closest_two_level(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+        if (!h.valid) break;
+        if (h.opaque) return 0.0f;      // (cannot happen: the any-hit pass would have returned; kept for the symmetry with shadow_resolve_candidates)
+        if (shadow_candidate_two_level(s, ray, h, st)) return 0.0f;
+        lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
+    }
+    return shadow_finish(ray, st);
+}
+template <class STACK>
+HRT_DEV float shadow_query_two_level(const SceneView& s, const GlobalBvhTl& bvh, const Ray& ray, STACK& stack, uint32_t nodeLoopMin = 0)
+{
+    bool sawNonOpaque;
+    if (any_hit_two_level(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque, nodeLoopMin)) return 0.0f;
+    return sawNonOpaque ? shadow_retrace_two_level(s, bvh, ray, stack) : 1.0f;
+}
+
 // Re-trace form: one closest-hit query per non-opaque candidate (validation megakernel).
 // ALL_OPAQUE: the scene is known (upload-time trait) to hold ForceOpaque instances only: the candidate pass is compiled out.
 template <bool ALL_OPAQUE = false, class BVH, class STACK>
 HRT_DEV float shadow_query(const SceneView& s, const BVH& bvh, f3 worldPos, f3 L, float maxDist, STACK& stack, uint32_t nodeLoopMin = 0)
 {
     Ray ray = shadow_ray(worldPos, L, maxDist);
-    if constexpr (BVH::kTwoLevel) return any_hit_two_level(bvh, s.rootLeaf, s.nodeCount, ray, stack, nodeLoopMin) ? 0.0f : 1.0f;
+    if constexpr (BVH::kTwoLevel) {
+        if constexpr (ALL_OPAQUE) { bool none; return any_hit_two_level(bvh, s.rootLeaf, s.nodeCount, ray, stack, none, nodeLoopMin) ? 0.0f : 1.0f; }
+        else return shadow_query_two_level(s, bvh, ray, stack, nodeLoopMin);
+    }
     // Any hit on a ForceOpaque instance commits -> 0, whatever lies in front of it.
     bool sawNonOpaque;
     if (any_opaque(bvh, s.rootLeaf, s.nodeCount, ray, stack, sawNonOpaque, nodeLoopMin)) return 0.0f;

@@ -333,7 +333,8 @@ constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot
 // instance opaque; the hit's instance goes to its own stream (hitInst) next to the hit record.
 // PRIMARY: bounce 0 of a batch without a raygen pass (WfArgs::primary): the refill derives the ray from the sample index. A separate instantiation:
 // as a run-time branch the extra live state cost the kernel 6 VGPRs and 3 % on EVERY bounce.
-template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, bool TL = false, bool PRIMARY = false>
+// TL: 0 flat tree, 1 two-level structure with ForceOpaque instances only, 2 two-level with non-opaque instances (candidate re-trace compiled in)
+template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, int TL = 0, bool PRIMARY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 : 5))) void wf_extend(WfArgs a, uint32_t parity)
 {
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
                             // compiled (ROCm 7.2, gfx950) to code that, on a tie in t won by (instance, primitive), took the new key but kept the OLD
                             // barycentrics: hits on an edge shared by two triangles then shaded with the other triangle's (u, v).
                             // tests/test_two_level_gpu.py::test_two_level_full_frame holds such a pixel; the select form is also 1 % faster.
-                            const bool take = hitTri && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));
+                            const bool ok = TL != 2 || !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);       // behind a rejected non-opaque candidate
+                            const bool take = hitTri && ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));
                             best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
                             best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
                             best.opaque = take ? iflags : best.opaque;
@@ -502,12 +504,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 :
                 } else if (cur == kTraversalDone) {
                     bool done = true;
                     HRT_PHASE(PH_EXT_FINISH);
-                    if (best.valid && !(best.opaque & 1u)) HRT_PHASE(PH_EXT_CANDIDATE);
-                    if (best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
+                    if (TL != 1 && best.valid && !(best.opaque & 1u)) HRT_PHASE(PH_EXT_CANDIDATE);
+                    if (TL != 1 && best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
                         // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
                         lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
                         best.valid = false; tlim = r.tmax; sp = 0;
                         cur = s.nodeCount == 0 ? s.rootLeaf : 0;
+                        if constexpr (TL) tl_world(tl, r);
                         done = false;
                     }
                     if (done) {
@@ -605,12 +608,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                         f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
                         float t, u, v;
                         const bool hitTri = tri_test(p0, p1, p2, r, sh, t, u, v);
-                        if (SHADOW) { if (hitTri) { blocked = true; break; } continue; }
+                        if (SHADOW) { if (hitTri) { if (I.flags & 1u) { blocked = true; break; } candCount = 1; } continue; }      // candCount: "crossed a non-opaque instance"
                         const uint32_t prim = __float_as_uint(tb.w);
-                        const bool take = hitTri && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see wf_extend<TL>
+                        const bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+                        const bool take = hitTri && ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see wf_extend<TL>
                         best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
                         best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
-                        best.valid = best.valid || take; best.opaque = 1u;
+                        best.valid = best.valid || take; best.opaque = take ? (I.flags & 1u) : best.opaque;
                         tlim = take ? t : tlim;
                     }
                     cur = blocked ? kTraversalDone : stack.pop(--sp);
@@ -655,7 +659,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                     if (finite) {
                         if (blocked) vis = 0.0f;
                         else if (candCount > 0) {
-                            if (LDS_BVH) vis = shadow_resolve_candidates(s, lbvh, r, sh, candCount, candOverflow, cand, stack);
+                            if constexpr (TL) vis = shadow_retrace_two_level(s, gbvh, r, stack);
+                            else if (LDS_BVH) vis = shadow_resolve_candidates(s, lbvh, r, sh, candCount, candOverflow, cand, stack);
                             else vis = shadow_resolve_candidates(s, gbvh, r, sh, candCount, candOverflow, cand, stack);
                         }
                     }
@@ -664,6 +669,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ?
                     lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
                     best.valid = false; tlim = r.tmax; sp = 0;
                     cur = s.nodeCount == 0 ? s.rootLeaf : 0;
+                    if constexpr (TL) tl_world(tl, r);
                     done = false;
                 } else if (best.valid) { out.t = best.t; out.u = best.u; out.v = best.v; out.instance = best.inst; out.primitive = best.prim; out.hit = 1u; out.rng = rng; }
                 if (done) {
@@ -1029,7 +1035,7 @@ enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadow
 // otherwise raise its register count past 170 and cost every scene with alpha-tested geometry a wave of occupancy; the resolve variant as
 // well: 185 -> 168 VGPRs, glass config shadow stage -6 %. Checked with 600 + 150 random trait scenes under HRPT_WF_SHADOW_PATH=2, because a
 // forced register budget has broken wf_shade's general variant twice)
-template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, bool TL = false>
+template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, int TL = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == 1 || MODE == 2) ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     static_assert(!TL || (!LDS_BVH && W == 4 && (MODE == kShadowOpaque || MODE == kShadowSlim)), "two-level structure: opaque any-hit query over the global tree");
@@ -1066,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE ==
                     if (!nee_direction<true>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ux, uy, L, maxDist)) return;
                     float shadow;
                     if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);
-                    else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
+                    else shadow = shadow_query<(TL != 2)>(s, gbvh, origin, L, maxDist, stack);
                     ++nRays;
                     if (shadow != 0.0f) {
                         const float4 th = a.primary ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(slot)) : a.b.thr[a.shadowParity][slot];
@@ -1125,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE ==
                         else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
                     } else {
                         if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);       // kShadowOpaque: no ForceNonOpaque instance in the scene
-                        else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
+                        else shadow = shadow_query<(TL != 2)>(s, gbvh, origin, L, maxDist, stack);
                     }
                     ++nRays;
                     if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped
@@ -1214,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 }
 
 // ------------------------------------------------------------------ host side
-struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; };
+struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; bool twoLevelCandidates = false; };
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
@@ -1251,22 +1257,25 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
         if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     }
 }
-template <int D> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
+template <int D, int TL> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
 {
-    if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, true>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+}
+template <int D, int TL> void launch_extend_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
+{
+    if (a.primary) hipLaunchKernelGGL((wf_extend<false, D, 4, false, TL, true>), g, dim3(kBlock), sh, st, a, parity);
+    else hipLaunchKernelGGL((wf_extend<false, D, 4, false, TL, false>), g, dim3(kBlock), sh, st, a, parity);
 }
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit = false)
 {
     if (v.twoLevel) {       // closest hits only (wavefront_render keeps the any-hit pass off for two-level scenes)
-        if (a.primary) {
-            if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
-            else if (v.depth <= 32) hipLaunchKernelGGL((wf_extend<false, 32, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
-            else hipLaunchKernelGGL((wf_extend<false, 64, 4, false, true, true>), g, dim3(kBlock), sh, st, a, parity);
-        } else if (v.depth <= 16) hipLaunchKernelGGL((wf_extend<false, 16, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
-        else if (v.depth <= 32) hipLaunchKernelGGL((wf_extend<false, 32, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
-        else hipLaunchKernelGGL((wf_extend<false, 64, 4, false, true>), g, dim3(kBlock), sh, st, a, parity);
+        if (v.twoLevelCandidates) {
+            if (v.depth <= 16) launch_extend_two_level<16, 2>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_two_level<32, 2>(g, sh, st, a, parity); else launch_extend_two_level<64, 2>(g, sh, st, a, parity);
+        } else {
+            if (v.depth <= 16) launch_extend_two_level<16, 1>(g, sh, st, a, parity); else if (v.depth <= 32) launch_extend_two_level<32, 1>(g, sh, st, a, parity); else launch_extend_two_level<64, 1>(g, sh, st, a, parity);
+        }
         return;
     }
     if (v.lds) launch_extend_l<true>(v, g, sh, st, a, parity, anyHit); else launch_extend_l<false>(v, g, sh, st, a, parity, anyHit);
@@ -1274,9 +1283,11 @@ void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
 void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
     if (v.twoLevel) {
-        if (v.depth <= 16) launch_shadow_two_level<16>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
-        else if (v.depth <= 32) launch_shadow_two_level<32>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
-        else launch_shadow_two_level<64>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        if (v.twoLevelCandidates) {
+            if (v.depth <= 16) launch_shadow_two_level<16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_two_level<32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_two_level<64, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        } else {
+            if (v.depth <= 16) launch_shadow_two_level<16, 1>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_two_level<32, 1>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_two_level<64, 1>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+        }
         return;
     }
     if (v.lds) launch_shadow_l<true>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_l<false>(v, g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
@@ -1533,7 +1544,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     auto pick = [&](int width, size_t extraBytes, int ldsStackMax) {
         Variant v; v.width = width;
         if (traits.twoLevelStackNeed) {      // two-level structure: 4-wide trees in global memory, its own kernels
-            v.width = 4; v.twoLevel = true; v.lds = false;
+            v.width = 4; v.twoLevel = true; v.lds = false; v.twoLevelCandidates = traits.hasNonOpaque;
             v.depth = traits.twoLevelStackNeed <= 16 ? 16 : (traits.twoLevelStackNeed <= 32 ? 32 : 64);
             v.ldsBytes = (size_t)(v.depth > ldsStackMax ? ldsStackMax : v.depth) * kBlock * 4 + st.padLdsBytes;
             return v;

@@ -23,7 +23,7 @@ def _rot(rng):
                      [2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, masked=False, far=0.0, sphere_res=(24, 12)):
+def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, masked=False, far=0.0, sphere_res=(24, 12), glass=False):
     """Floor + n_side^2 instances of two meshes (a sphere and a capped-less cylinder) with random rotations, non-uniform scales and a few
     materials; `far` shifts the whole scene away from the origin (large world coordinates against small object coordinates)."""
     rng = np.random.default_rng(seed)
@@ -42,6 +42,10 @@ def instanced_scene(luts, n_side=12, seed=5, lights="sun", textured=False, maske
         tex = b.add_texture(scenes.procedural_texture(rng, 64, "alpha"))
         mats.append(b.add_material(m_BaseColor=(1, 1, 1, 1), m_TextureFlags=S.TEXFLAG_ALBEDO, m_AlbedoTextureIndex=tex,
                                    m_AlphaMode=S.ALPHA_MODE_MASK, m_AlphaCutoff=0.5))
+    if glass:
+        mats.append(b.add_material(m_BaseColor=(0.9, 0.95, 1.0, 1.0), m_RoughnessMetallic=(0.05, 0.0), m_TransmissionFactor=0.9, m_IOR=1.5, m_AlphaMode=S.ALPHA_MODE_BLEND,
+                                   m_SigmaA=(0.4, 0.1, 0.05), m_IsThinSurface=0))
+        mats.append(b.add_material(m_BaseColor=(0.6, 0.8, 0.6, 0.4), m_AlphaMode=S.ALPHA_MODE_BLEND))       # stochastic alpha
     span = 1.4 * n_side
     b.add_instance(quad, mats[0], scenes._mat((span + 4, 1, span + 4), None, (far, 0, far)))
     for i in range(n_side):
@@ -248,15 +252,47 @@ def test_instance_flattened_to_a_plane_is_built_flat(luts):
     assert i_two.structure == S.ACCEL_FLAT and n_flat == n_two and np.array_equal(a_flat.view(np.uint32), a_two.view(np.uint32))
 
 
-def test_scene_with_alpha_tested_instances_is_built_flat(luts):
-    """Two-level needs every instance ForceOpaque; asking for it on a scene with MASK materials yields the flat tree (and correct frames)."""
-    n = 6
-    sc = instanced_scene(luts, n, seed=2, masked=True)
-    view, pos = _camera(96, 64, n)
-    a_flat, n_flat, _, _ = _render(luts, sc, S.ACCEL_FLAT, 96, 64, 2, 3, view, pos)
-    a_two, n_two, info, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, 96, 64, 2, 3, view, pos)
-    assert info.structure == S.ACCEL_FLAT
-    assert n_flat == n_two and np.array_equal(a_flat.view(np.uint32), a_two.view(np.uint32))
+@pytest.mark.parametrize("kind", ["mask", "glass", "mask+glass+three-lights"])
+def test_two_level_with_non_opaque_instances(luts, kind):
+    """Instances whose material is MASK (alpha-tested texture) or BLEND / transmissive (glass with absorption): closest hits re-trace behind a
+    rejected candidate, shadow rays take the any-hit pass over the opaque instances and then visit the crossed non-opaque triangles front to
+    back -- the same order as every other form of the query, hence the same bits as the flat structure (and the same RNG draws for stochastic
+    alpha)."""
+    n = 10
+    sc = instanced_scene(luts, n, seed=17, masked="mask" in kind, glass="glass" in kind, lights="three" if "three" in kind else "sun")
+    view, pos = _camera(160, 96, n)
+    _same_frames(luts, sc, 160, 96, 3, 6, view, pos)
+
+
+def test_ray_queries_over_a_two_level_scene_with_non_opaque_instances(luts):
+    from hobbyrenderer_amd.native import PathTracerContext
+    n = 10
+    sc = instanced_scene(luts, n, seed=19, masked=True, glass=True)
+    rng = np.random.default_rng(4)
+    m = 30000
+    rays = np.zeros(m, S.Ray)
+    rays["origin"] = (rng.random((m, 3)).astype(np.float32) - np.float32(0.5)) * np.float32([1.6 * n, 5.0, 1.6 * n]) + np.float32([0, 2.5, 0])
+    d = rng.normal(size=(m, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["direction"] = d
+    rays["tmax"] = np.where(rng.random(m) < 0.6, 1e10, rng.random(m) * 10).astype(np.float32)
+    rays["rng"] = rng.integers(0, 2 ** 32, m, dtype=np.uint64).astype(np.uint32)
+    out = {}
+    for mode in (S.ACCEL_FLAT, S.ACCEL_TWO_LEVEL):
+        c = PathTracerContext(0)
+        try:
+            c.set_acceleration_structure(mode)
+            c.upload_scene(sc)
+            assert c.build_info().structure == mode
+            out[mode] = (c.trace_rays(rays), c.trace_rays(rays, shadow=True))
+        finally:
+            c.close()
+    (hf, vf), (ht, vt) = out[S.ACCEL_FLAT], out[S.ACCEL_TWO_LEVEL]
+    assert (hf["rng"] != rays["rng"]).any() and ((vf["t"] > 0) & (vf["t"] < 1)).any()        # stochastic alpha drew numbers; partial visibility through glass
+    for f in ("hit", "instance", "primitive", "rng"):
+        assert np.array_equal(hf[f], ht[f]), f
+    for f in ("t", "u", "v"):
+        assert np.array_equal(hf[f].view(np.uint32), ht[f].view(np.uint32)), f
+    assert np.array_equal(vf["t"].view(np.uint32), vt["t"].view(np.uint32))
 
 
 def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
@@ -278,13 +314,13 @@ def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
         rays["tmax"] = 10
         with pytest.raises(HrptError):
             c.trace_rays(rays, thread_per_ray=True)         # the persistent kernel does (test_ray_queries_over_the_two_level_structure)
-        # a material change that makes an instance non-opaque rebuilds the structure flat
+        # a material change that makes an instance non-opaque rebuilds the structure (instance flags), still two-level
         m = sc.materials.copy()
         m["m_AlphaMode"][1] = S.ALPHA_MODE_BLEND
         m["m_BaseColor"][1, 3] = 0.5
         c.update_materials(m)
-        assert c.build_info().structure == S.ACCEL_FLAT
-        c.render(scenes.fill_constants(view, pos, sc, 0, 2), accum_count=1, flags=S.FRAME_MEGAKERNEL)
+        assert c.build_info().structure == S.ACCEL_TWO_LEVEL
+        c.render(scenes.fill_constants(view, pos, sc, 0, 2), accum_count=1)
         c.synchronize()
     finally:
         c.close()
