@@ -196,6 +196,78 @@ HRT_DEV float shadow_retrace_two_level(const SceneView& s, const GlobalBvhTl& bv
     }
     return shadow_finish(ray, st);
 }
+// Buffered form over the two-level structure (wf_shadow<TL = 2>): ONE traversal that returns at the first triangle of an opaque instance and keeps
+// the K nearest triangles of non-opaque instances, sorted by (t, instance, primitive), in per-lane LDS columns CAND3 of (t, mesh triangle,
+// instance); they are then visited front to back, and only a ray that crossed more than K continues with the re-trace loop behind the K-th.
+// Same visiting order as shadow_query_two_level, hence the same result.
+template <int K, class STACK, class CAND3>
+HRT_DEV float shadow_query_two_level_buffered(const SceneView& s, const GlobalBvhTl& bvh, const Ray& ray, STACK& stack, CAND3& cand, uint32_t nodeLoopMin = 0)
+{
+    if (!(ray.d.x == ray.d.x && ray.d.y == ray.d.y && ray.d.z == ray.d.z)) return 1.0f;
+    RayShear sh = make_shear(ray.d);
+    TlCull c; tl_world(c, ray);
+    int sp = 0, count = 0; bool overflow = false;
+    int32_t cur;
+    if (s.nodeCount == 0) { if (s.rootLeaf == 0) return 1.0f; cur = s.rootLeaf; } else cur = 0;
+    auto prim_of = [&](uint32_t tri) { return reinterpret_cast<const uint32_t*>(bvh.tris + tri)[7]; };      // GpuTri::prim
+    for (;;) {
+        while (cur >= 0 && cur != kExitBlas) {
+            cur = inner_step(bvh, cur, c.noi, c.noiF, c.inv, ray.tmin, ray.tmax, stack, sp);
+            if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != kExitBlas)) < nodeLoopMin) break;
+        }
+        if (cur == kTraversalDone) break;
+        if (cur == kExitBlas || (cur < 0 && c.inst < 0)) { cur = tl_switch(bvh, cur, c, ray, stack, sp); continue; }
+        if (cur >= 0) continue;
+        const GpuInstance& I = bvh.instances[c.inst];
+        const uint32_t enc = (uint32_t)(~cur), first = enc >> 2, n = (enc & 3u) + 1u, inst = (uint32_t)c.inst;
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 ta, tb, tc; bvh.tri(first + i, ta, tb, tc);
+            f3 p0, p1, p2; tl_world_triangle(I, ta, tb, tc, p0, p1, p2);
+            float t, u, v;
+            if (!tri_test(p0, p1, p2, ray, sh, t, u, v)) continue;
+            if (I.flags & 1u) return 0.0f;                                        // opaque instance: committed
+            const uint32_t prim = __float_as_uint(tb.w);
+            int pos = count;
+            if (count == K) {
+                float lt; uint32_t ltri, linst; cand.key(K - 1, lt, ltri, linst);
+                overflow = true;
+                if (!key_less(t, inst, prim, lt, linst, prim_of(ltri))) continue;
+                pos = K - 1;
+            } else ++count;
+            while (pos > 0) {
+                float pt; uint32_t ptri, pinst; cand.key(pos - 1, pt, ptri, pinst);
+                const bool less = t != pt ? t < pt : key_less(t, inst, prim, pt, pinst, prim_of(ptri));
+                if (!less) break;
+                cand.move(pos, pos - 1);
+                --pos;
+            }
+            cand.set(pos, t, first + i, inst);
+        }
+        cur = stack.pop(--sp);
+    }
+    if (count == 0) return 1.0f;
+    ShadowState st; st.transmission = 1.0f; st.inVolume = false; st.inVolumeStartT = 0.0f; st.sigmaT = mk3(0.0f, 0.0f, 0.0f);
+    Hit h; h.valid = true; h.opaque = 0; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.inst = 0; h.prim = 0;
+    for (int k = 0; k < count; ++k) {
+        float kt; cand.key(k, kt, h.tri, h.inst);
+        float4 ta, tb, tc; bvh.tri(h.tri, ta, tb, tc);
+        f3 p0, p1, p2; tl_world_triangle(bvh.instances[h.inst], ta, tb, tc, p0, p1, p2);
+        tri_test(p0, p1, p2, ray, sh, h.t, h.u, h.v);                               // recomputes (t, u, v) bit for bit
+        h.prim = __float_as_uint(tb.w);
+        if (shadow_candidate_two_level(s, ray, h, st)) return 0.0f;
+    }
+    if (overflow) {   // more than K candidates: continue behind the K-th with the re-trace loop
+        HitKey lower; lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
+        for (;;) {
+            Hit n = closest_two_level(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+            if (!n.valid) break;
+            if (n.opaque) return 0.0f;
+            if (shadow_candidate_two_level(s, ray, n, st)) return 0.0f;
+            lower.t = n.t; lower.inst = n.inst; lower.prim = n.prim;
+        }
+    }
+    return shadow_finish(ray, st);
+}
 template <class STACK>
 HRT_DEV float shadow_query_two_level(const SceneView& s, const GlobalBvhTl& bvh, const Ray& ray, STACK& stack, uint32_t nodeLoopMin = 0)
 {

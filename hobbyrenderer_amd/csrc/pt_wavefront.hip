@@ -163,6 +163,14 @@ struct LdsCandidates {
     HRT_DEV void set(int k, float t, uint32_t tri) { base[(k * 2 + 0) * kBlock] = __float_as_int(t); base[(k * 2 + 1) * kBlock] = (int32_t)tri; }
     HRT_DEV void move(int dst, int src) { base[(dst * 2 + 0) * kBlock] = base[(src * 2 + 0) * kBlock]; base[(dst * 2 + 1) * kBlock] = base[(src * 2 + 1) * kBlock]; }
 };
+// ... with the instance next to the triangle (two-level structure: the triangle index is per mesh): entry k at base[(k*3 + {0,1,2}) * kBlock]
+constexpr int kTwoLevelCandidates = 4;
+struct LdsCandidates3 {
+    int32_t* base;
+    HRT_DEV void key(int k, float& t, uint32_t& tri, uint32_t& inst) const { t = __int_as_float(base[(k * 3 + 0) * kBlock]); tri = (uint32_t)base[(k * 3 + 1) * kBlock]; inst = (uint32_t)base[(k * 3 + 2) * kBlock]; }
+    HRT_DEV void set(int k, float t, uint32_t tri, uint32_t inst) { base[(k * 3 + 0) * kBlock] = __float_as_int(t); base[(k * 3 + 1) * kBlock] = (int32_t)tri; base[(k * 3 + 2) * kBlock] = (int32_t)inst; }
+    HRT_DEV void move(int dst, int src) { for (int w = 0; w < 3; ++w) base[(dst * 3 + w) * kBlock] = base[(src * 3 + w) * kBlock]; }
+};
 // candidate list of one shadow ray in global memory (written by wf_extend<ANYHIT> when the ray finishes, read by wf_shadow)
 struct GlobalCandidates {
     const uint2* base;
@@ -1048,6 +1056,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE ==
     setup_lds<LDS_BVH, DEPTH, W>(smem, a.scene, stack, lbvh, candBytes);
     if (DEPTH > kLdsMax) { stack.spill = a.spill[1] + blockIdx.x * kBlock + threadIdx.x; stack.spillStride = gridDim.x * kBlock; }
     LdsCandidates cand; cand.base = reinterpret_cast<int32_t*>(smem + (size_t)LdsStack<DEPTH, kLdsMax>::kRows * kBlock * 4) + threadIdx.x;
+    LdsCandidates3 cand3; cand3.base = cand.base;        // TL == 2: (t, mesh triangle, instance) columns in the same place (the launch adds their bytes)
     typename GlobalBvhOf<(TL ? kTwoLevelTree : W)>::type gbvh = GlobalBvhOf<(TL ? kTwoLevelTree : W)>::make(a.scene);
     const SceneView& s = a.scene;
     const f3 sunDir = mk3(cb.m_SunDirection[0], cb.m_SunDirection[1], cb.m_SunDirection[2]);
@@ -1072,7 +1081,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE ==
                     if (!nee_direction<true>(l, N, origin, sunDir, cb.m_CosSunAngularRadius, ux, uy, L, maxDist)) return;
                     float shadow;
                     if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);
-                    else shadow = shadow_query<(TL != 2)>(s, gbvh, origin, L, maxDist, stack);
+                    else if constexpr (TL == 2) shadow = shadow_query_two_level_buffered<kTwoLevelCandidates>(s, gbvh, shadow_ray(origin, L, maxDist), stack, cand3);
+                    else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
                     ++nRays;
                     if (shadow != 0.0f) {
                         const float4 th = a.primary ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(slot)) : a.b.thr[a.shadowParity][slot];
@@ -1131,7 +1141,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE ==
                         else shadow = shadow_query_buffered<kShadowCandidates>(s, gbvh, origin, L, maxDist, stack, cand);
                     } else {
                         if (LDS_BVH) shadow = shadow_query<true>(s, lbvh, origin, L, maxDist, stack);       // kShadowOpaque: no ForceNonOpaque instance in the scene
-                        else shadow = shadow_query<(TL != 2)>(s, gbvh, origin, L, maxDist, stack);
+                        else if constexpr (TL == 2) shadow = shadow_query_two_level_buffered<kTwoLevelCandidates>(s, gbvh, shadow_ray(origin, L, maxDist), stack, cand3);
+                    else shadow = shadow_query<true>(s, gbvh, origin, L, maxDist, stack);
                     }
                     ++nRays;
                     if (shadow != 0.0f) {   // an occluded sample contributes +0: its BRDF x radiance evaluation is skipped
@@ -1259,6 +1270,7 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
 }
 template <int D, int TL> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
 {
+    if (TL == 2) sh += (size_t)kTwoLevelCandidates * 3 * kBlock * 4;      // candidate columns of the buffered two-level shadow query
     if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
     else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
     else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);

@@ -334,10 +334,9 @@ int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
  * decided in world space on the world-space vertices the flat upload would produce, non-opaque instances (MASK / BLEND / transmissive
  * materials) included: their candidates are visited in the same front-to-back order. Two-level runs on the wavefront pipeline and the
  * persistent ray-query kernel only (HRPT_FRAME_MEGAKERNEL, HRPT_RAYS_THREAD_PER_RAY and hrpt_selftest_bvh answer HRPT_ERR_INVALID_ARGUMENT
- * on such a scene); its shadow query re-traces once per crossed non-opaque triangle where the flat structure buffers candidates, so scenes
- * of alpha-tested or glass instances render 2-3x slower in their shadow stage than flat -- the trade is memory. A scene that cannot be held
+ * on such a scene). A scene that cannot be held
  * in this form (an instance whose world matrix has no inverse, now or after a later hrpt_update_instances) is built flat whatever was
- * asked -- HrptBuildInfo::structure tells. AUTO: two-level when the scene has at least 2 M world triangles (64 M if any instance is non-opaque) and at least 8
+ * asked -- HrptBuildInfo::structure tells. AUTO: two-level when the scene has at least 2 M world triangles (16 M if any instance is non-opaque: measured cross-over) and at least 8
  * instances per distinct mesh on average (measured on MI355X, opaque spheres / cylinders of ~400 triangles, 1920x1080, 8 spp, 4 bounces:
  * 4 096 instances 19.7 ms flat vs 19.0 ms two-level, 16 384: 27.7 vs 20.2 ms, 65 536: 44.0 vs 21.5 ms and 17.6 GB vs 30 MB -- the small trees stay in cache).
  * Takes effect at the next hrpt_upload_scene. */

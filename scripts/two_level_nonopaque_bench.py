@@ -5,7 +5,7 @@ from hobbyrenderer_amd import native, scenes, structs as S
 from test_two_level_gpu import instanced_scene, _camera
 luts = native.precompute_atmosphere()
 W, H, SPP, B = 1920, 1080, 8, 4
-for n in (64, 128):
+for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
     sc = instanced_scene(luts, n, seed=3, masked=True, glass=True)
     view, pos = _camera(W, H, n); cb = scenes.fill_constants(view, pos, sc, 0, B); ref = None
     for name, mode in (("flat", S.ACCEL_FLAT), ("two-level", S.ACCEL_TWO_LEVEL)):
