@@ -18,3 +18,5 @@ run "class sort forced on" 400 HRPT_WF_SHADE_SORT=1
 run "class sort forced off" 400 HRPT_WF_SHADE_SORT=0
 run "raygen pass kept (HRPT_WF_FUSED_PRIMARY=0)" 200 HRPT_WF_FUSED_PRIMARY=0
 run "slim shadow entries off" 200 HRPT_WF_SLIM_SHADOW=0
+out=$(env HRPT_TEST_TWO_LEVEL_SEEDS=300 timeout -k 10 1000 python -m pytest tests/test_two_level_gpu.py -x -q -k random_scenes 2>&1 | tail -1)
+echo "two-level structure against the flat one (random instanced scenes: opaque / textured / MASK / glass / stochastic alpha, 1 or 3 lights, up to 4000 units from the origin): 300 scenes: $out"

@@ -264,6 +264,24 @@ def test_two_level_with_non_opaque_instances(luts, kind):
     _same_frames(luts, sc, 160, 96, 3, 6, view, pos)
 
 
+def test_two_level_random_scenes(luts):
+    """Random instanced scenes (HRPT_TEST_TWO_LEVEL_SEEDS of them, 24 by default): instance count, materials (opaque / textured / MASK / glass /
+    stochastic alpha), lights, distance from the origin, camera and bounce count drawn per seed; two-level == flat bit for bit."""
+    import os
+    for seed in range(int(os.environ.get("HRPT_TEST_TWO_LEVEL_SEEDS", "24"))):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(2, 14))
+        kw = dict(lights="three" if rng.random() < 0.4 else "sun", textured=bool(rng.random() < 0.4), masked=bool(rng.random() < 0.4),
+                  glass=bool(rng.random() < 0.4), far=float(rng.choice([0.0, 0.0, 300.0, 4000.0])))
+        sc = instanced_scene(luts, n, seed=seed, **kw)
+        w, h = int(rng.integers(5, 14)) * 8 + int(rng.integers(0, 8)), int(rng.integers(4, 10)) * 8 + int(rng.integers(0, 8))
+        view, pos = _camera(w, h, n, far=kw["far"])
+        try:
+            _same_frames(luts, sc, w, h, int(rng.integers(1, 4)), int(rng.integers(1, 7)), view, pos)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: n={n} {kw} {w}x{h}: {e}") from e
+
+
 def test_ray_queries_over_a_two_level_scene_with_non_opaque_instances(luts):
     from hobbyrenderer_amd.native import PathTracerContext
     n = 10
