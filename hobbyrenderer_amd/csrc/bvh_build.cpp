@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <numeric>
 
@@ -37,21 +38,27 @@ struct Builder {
 
     static int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1)); }
 
-    int32_t make_leaf(uint32_t first, uint32_t count)
+    int32_t make_leaf(BuiltBvh& o, uint32_t first, uint32_t count)
     {
-        uint32_t base = (uint32_t)out->tris.size();
-        for (uint32_t i = 0; i < count; ++i) out->tris.push_back((*src)[prims[first + i].tri]);
+        uint32_t base = (uint32_t)o.tris.size();
+        for (uint32_t i = 0; i < count; ++i) o.tris.push_back((*src)[prims[first + i].tri]);
         return encode_leaf(base, count);
     }
 
-    // returns child reference (>= 0 inner node, < 0 leaf) and its padded bounds
-    int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds)
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds) { return build(*out, first, count, depth, bounds, kParallelLevels); }
+
+    // returns child reference (>= 0 inner node, < 0 leaf) and its padded bounds. `forks`: levels below which the right subtree may still be built
+    // by another thread (into its own arrays, spliced behind the left subtree: nodes and triangles end up exactly where the sequential build puts
+    // them -- depth-first order -- so the tree does not depend on the thread count).
+    static constexpr int kParallelLevels = 4;              // up to 16 threads
+    static constexpr uint32_t kParallelMin = 8192;         // primitives in a range worth a thread
+    int32_t build(BuiltBvh& o, uint32_t first, uint32_t count, uint32_t depth, Box& bounds, int forks)
     {
-        out->maxDepth = std::max(out->maxDepth, depth);
+        o.maxDepth = std::max(o.maxDepth, depth);
         Box b, cb;
         for (uint32_t i = first; i < first + count; ++i) { b.grow(prims[i].bmin, prims[i].bmax); cb.grow(prims[i].c, prims[i].c); }
         bounds = b;
-        if (count <= minLeaf) return make_leaf(first, count);
+        if (count <= minLeaf) return make_leaf(o, first, count);
 
         uint32_t log2c = 0; while ((1u << log2c) < count) ++log2c;
         bool forceMedian = depth + log2c + 2 >= kHostBuilderDepthGoal;
@@ -79,7 +86,7 @@ struct Builder {
                 }
             }
         }
-        if (!forceMedian && count <= maxLeaf && (bestAxis < 0 || bestCost >= leafCost)) return make_leaf(first, count);
+        if (!forceMedian && count <= maxLeaf && (bestAxis < 0 || bestCost >= leafCost)) return make_leaf(o, first, count);
 
         uint32_t mid;
         if (bestAxis >= 0 && !forceMedian) {
@@ -100,12 +107,27 @@ struct Builder {
                 return a.tri < c.tri;
             });
         }
-        int32_t id = (int32_t)out->nodes.size();
-        out->nodes.emplace_back();
+        int32_t id = (int32_t)o.nodes.size();
+        o.nodes.emplace_back();
         Box lb, rb;
-        int32_t l = build(first, mid - first, depth + 1, lb);
-        int32_t r = build(mid, first + count - mid, depth + 1, rb);
-        HostNode& n = out->nodes[id];
+        int32_t l, r;
+        if (forks > 0 && count >= kParallelMin) {
+            BuiltBvh ro;
+            auto right = std::async(std::launch::async, [&]() { return build(ro, mid, first + count - mid, depth + 1, rb, forks - 1); });
+            l = build(o, first, mid - first, depth + 1, lb, forks - 1);
+            r = right.get();
+            const int32_t nodeOff = (int32_t)o.nodes.size(); const uint32_t triOff = (uint32_t)o.tris.size();
+            auto moved = [&](int32_t ref) { if (ref >= 0) return ref + nodeOff; const uint32_t enc = (uint32_t)~ref; return ~(int32_t)((((enc >> 2) + triOff) << 2) | (enc & 3u)); };
+            for (HostNode& rn : ro.nodes) { rn.left = moved(rn.left); rn.right = moved(rn.right); }
+            o.nodes.insert(o.nodes.end(), ro.nodes.begin(), ro.nodes.end());
+            o.tris.insert(o.tris.end(), ro.tris.begin(), ro.tris.end());
+            o.maxDepth = std::max(o.maxDepth, ro.maxDepth);
+            r = moved(r);
+        } else {
+            l = build(o, first, mid - first, depth + 1, lb, 0);
+            r = build(o, mid, first + count - mid, depth + 1, rb, 0);
+        }
+        HostNode& n = o.nodes[id];
         for (int k = 0; k < 3; ++k) { n.lmin[k] = lb.mn[k]; n.lmax[k] = lb.mx[k]; n.rmin[k] = rb.mn[k]; n.rmax[k] = rb.mx[k]; }
         n.left = l; n.right = r; n.pad0 = 0; n.pad1 = 0;
         return id;

@@ -299,7 +299,7 @@ int  hrpt_set_stream(HrptContext* ctx, void* hipStream, int useCallerStream);
 int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output);
 /* ---- acceleration-structure builder --------------------------------------------------------------
  * Scene::BuildAccelerationStructures (src/Scene.cpp:67-214) is a driver BLAS/TLAS build in the reference. Here
- * hrpt_upload_scene builds the library's own structure either on the host (binned SAH: the best tree, ~0.5 s per million
+ * hrpt_upload_scene builds the library's own structure either on the host (binned SAH on up to 16 host threads: the best tree, ~0.25 s per million
  * triangles) or on the GPU (Morton-order LBVH or PLOC clustering: milliseconds). Radiance is identical either way (the hit
  * definition is BVH-independent). The GPU builders fall back to the host one for scenes under 8 triangles or when their
  * tree is deeper than the traversal stacks allow. The default, HRPT_BVH_BUILDER_AUTO, takes the host builder below 65 536
