@@ -21,6 +21,8 @@ for cfg in 2 4 5; do
 done
 python3 scripts/ray_query_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/ray_query_bench.txt
 python3 scripts/two_level_bench.py 64 128 256 2>&1 | grep -v amdgpu.ids > $OUT/two_level_bench.txt
+python3 scripts/two_level_nonopaque_bench.py 64 128 256 2>&1 | grep -v amdgpu.ids > $OUT/two_level_nonopaque_bench.txt
+python3 scripts/bvh_builder_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/bvh_builder_bench.txt
 for l in 2 3; do for n in 8 4 2; do LANES=$l python3 scripts/shard_host_overhead_probe.py $n 2>&1 | grep "N=" | tail -1 | sed "s/^/lanes=$l /"; done; done > $OUT/shard_probe.txt
 cut -c1-160 $OUT/rocprofv3_kernel_stats.csv | head -12
 python3 - <<'PY'
