@@ -1,0 +1,48 @@
+"""The bench line's contract (the driver parses it): checked on the committed lines of the round (profiles/r02_bench_*.json, written by
+`python bench.py [--config N]` on an MI355X) and on bench.py's command line. No GPU needed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name,config", [("r02_bench_n1.json", 2), ("r02_bench_config2.json", 2), ("r02_bench_config4.json", 4), ("r02_bench_config5.json", 5)])
+def test_committed_bench_lines_keep_the_contract(name, config):
+    d = _line(name)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "Mrays/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] >= 1 and d["scaling"] == "strong" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["config"]["baseline_config"] == config and d["config"]["baseline_parameters"] is True and "workload" in d["config"] and "model" not in d["config"]
+    # value = rays of a step / time of a step
+    assert d["value"] == pytest.approx(d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3, rel=1e-6)
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] <= 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    # achieved = queue bytes of the dominant class per launch / its launch time
+    assert r["achieved"] == pytest.approx(r["queue_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert 0.0 < r["whole_step"]["frac"] <= 1.0
+    assert r["traffic"] is None or (r["traffic_source"] and "profiles/" in r["traffic_source"])
+    if r["traffic"] is not None:       # counted queue bytes against the PMC figure of the same launches: about equal when the tree is LDS-resident
+        ratio = r["queue_bytes_per_launch"] / r["traffic"]        # (config 2); with the tree in global memory its nodes and triangles add HBM traffic
+        assert (0.8 < ratio < 1.25) if config == 2 else (0.2 < ratio < 1.25), ratio
+    assert set(r["kernels"]) >= {"wf_extend", "wf_shade", "wf_shadow", "wf_resolve"}
+    assert "algorithmic_model" in r and r["algorithmic_model"]["bytes_per_step"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
+    assert d["one_frame_in_flight"]["ms_per_step"] >= d["ms_per_step"] * 0.9
+
+
+def test_bench_command_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--serial-kernels", "--frames-in-flight"):
+        assert flag in out.stdout
