@@ -391,7 +391,9 @@ def main():
             at_baseline = world == 1 and (W, H, spp, bounces) == (1920, 1080, base_spp, base_bounces)
             # config 5's counters were collected at 8 of its 64 spp (per-launch figures do not depend on the spp count beyond the batch size)
             traffic = None
-            if at_baseline and traffic_doc:
+            # (config 5's PMC passes run at 8 of its 64 spp -- an eighth of the bytes per launch -- and list the three kernels of its shadow stage
+            # separately: no per-launch figure comparable with `queue_bytes_per_launch` here; profiles/r02_pmc_config5.txt has the per-kernel bytes)
+            if at_baseline and traffic_doc and args.config != 5:
                 # launch-weighted over the instantiations of the class (the bounce-0 ones of a batch without raygen pass are listed as *_primary)
                 rows = [v for k, v in traffic_doc.items() if k in (kernel, kernel + "_primary") and v.get("hbm_bytes_per_launch") is not None]
                 n = sum(v.get("launches_sampled", 1) for v in rows)
