@@ -412,7 +412,8 @@ def main():
                                "timed_region_GBps": all_bytes / prof_steps / (elapsed / args.steps) / 1e9,
                                "timed_region_frac": all_bytes / prof_steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
                 "kernels": kernel_times,
-                "valu": ({**valu_doc.get(kernel, {}), "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"}
+                "valu": ({**valu_doc.get(kernel, {}), "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run"
+                          + ("; taken at 8 of the 64 spp, and for the kernel of that name only: the shadow stage's ray generation and any-hit pass have rows of their own in the file" if args.config == 5 else "") + ")"}
                          if (valu_doc and at_baseline) else None),
                 "algorithmic_model": model,
                 "queue_pool_bytes": int(pst.queuePoolBytes),
