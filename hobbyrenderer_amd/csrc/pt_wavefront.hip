@@ -826,7 +826,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MAXL !=
                 ps.rng = __float_as_uint(d.w);
                 ps.throughput = mk3(t.x, t.y, t.z); smp = __float_as_uint(t.w);
                 ps.radiance = mk3(0.0f, 0.0f, 0.0f);   // contributions of THIS stage; added to sampleRadiance below
-                if (a.hasMedium) {
+                if (!SIMPLE && a.hasMedium) {
                     float4 m0 = a.b.med0[in][slot], m1 = a.b.med1[in][slot];
                     ps.sigmaA = mk3(m0.x, m0.y, m0.z); ps.interiorIOR = m0.w; ps.sigmaS = mk3(m1.x, m1.y, m1.z); ps.inVolume = m1.w != 0.0f;
                 } else { ps.sigmaA = mk3(0.0f, 0.0f, 0.0f); ps.sigmaS = mk3(0.0f, 0.0f, 0.0f); ps.interiorIOR = 1.0f; ps.inVolume = false; }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MAXL !=
                 a.b.rayO[out][o] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tmin);
                 a.b.rayD[out][o] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(ps.rng));
                 a.b.thr[out][o] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, __uint_as_float(smp));
-                if (a.hasMedium) {
+                if (!SIMPLE && a.hasMedium) {
                     a.b.med0[out][o] = make_float4(ps.sigmaA.x, ps.sigmaA.y, ps.sigmaA.z, ps.interiorIOR);
                     a.b.med1[out][o] = make_float4(ps.sigmaS.x, ps.sigmaS.y, ps.sigmaS.z, ps.inVolume ? 1.0f : 0.0f);
                 }
