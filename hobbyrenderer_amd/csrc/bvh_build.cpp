@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <system_error>
 #include <limits>
 #include <numeric>
 
@@ -113,9 +114,11 @@ struct Builder {
         int32_t l, r;
         if (forks > 0 && count >= kParallelMin) {
             BuiltBvh ro;
-            auto right = std::async(std::launch::async, [&]() { return build(ro, mid, first + count - mid, depth + 1, rb, forks - 1); });
+            std::future<int32_t> right;
+            try { right = std::async(std::launch::async, [&]() { return build(ro, mid, first + count - mid, depth + 1, rb, forks - 1); }); }
+            catch (const std::system_error&) {}                     // no thread to be had: this one builds both halves
             l = build(o, first, mid - first, depth + 1, lb, forks - 1);
-            r = right.get();
+            r = right.valid() ? right.get() : build(ro, mid, first + count - mid, depth + 1, rb, 0);
             const int32_t nodeOff = (int32_t)o.nodes.size(); const uint32_t triOff = (uint32_t)o.tris.size();
             auto moved = [&](int32_t ref) { if (ref >= 0) return ref + nodeOff; const uint32_t enc = (uint32_t)~ref; return ~(int32_t)((((enc >> 2) + triOff) << 2) | (enc & 3u)); };
             for (HostNode& rn : ro.nodes) { rn.left = moved(rn.left); rn.right = moved(rn.right); }
