@@ -205,7 +205,7 @@ static bool two_level_wanted(const HrptContext* c, const HrptSceneDesc& s, uint6
     std::vector<uint8_t> used(s.meshDataCount, 0); uint32_t distinct = 0;
     for (uint32_t i = 0; i < s.instanceCount; ++i) if (!used[s.instances[i].m_MeshDataIndex]) { used[s.instances[i].m_MeshDataIndex] = 1; ++distinct; }
     // scenes with non-opaque instances: measured cross-over against the flat structure at ~16 M world triangles (instanced alpha-tested + glass
-    // meshes: 7.6 M triangles 38 vs 33 ms, 30 M 41 vs 46 ms; the two-level candidate buffer holds 4 entries with the instance next to the triangle)
+    // meshes: 7.6 M triangles 35.5 vs 32.3 ms, 30 M 38 vs 46 ms; the two-level candidate buffer holds 4 entries with the instance next to the triangle)
     bool nonOpaque = false;
     for (uint32_t i = 0; i < s.instanceCount && !nonOpaque; ++i) nonOpaque = s.materials[s.instances[i].m_MaterialIndex].m_AlphaMode != HRPT_ALPHA_MODE_OPAQUE;
     return sceneTris >= (nonOpaque ? (16ull << 20) : (2ull << 20)) && (uint64_t)s.instanceCount >= 8ull * distinct;

@@ -1042,9 +1042,10 @@ enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadow
 // (the buffered variant is held at 3 waves per SIMD: the gradient-sampled alpha test of mip-mapped MASK textures -- a rare path -- would
 // otherwise raise its register count past 170 and cost every scene with alpha-tested geometry a wave of occupancy; the resolve variant as
 // well: 185 -> 168 VGPRs, glass config shadow stage -6 %. Checked with 600 + 150 random trait scenes under HRPT_WF_SHADOW_PATH=2, because a
-// forced register budget has broken wf_shade's general variant twice)
+// forced register budget has broken wf_shade's general variant twice; the two-level variants too: 183..248 -> 168 VGPRs, scenes with non-opaque
+// instances -16 % shadow time, 300 random two-level scenes against the flat structure)
 template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, int TL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == 1 || MODE == 2) ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == 1 || MODE == 2 || TL != 0) ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     static_assert(!TL || (!LDS_BVH && W == 4 && (MODE == kShadowOpaque || MODE == kShadowSlim)), "two-level structure: opaque any-hit query over the global tree");
     constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;
