@@ -330,6 +330,15 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // Persistent while-while traversal with lane refill: a wave keeps up to 64 rays of its segment in flight; whenever
 // at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
+#ifndef HRT_X_TL
+#define HRT_X_TL 4
+#endif
+#ifndef HRT_X_EXT
+#define HRT_X_EXT 5
+#endif
+#ifndef HRT_X_SIMPLE
+#define HRT_X_SIMPLE 4
+#endif
 constexpr uint32_t kRefillMinDefault = 12;
 constexpr uint32_t kShadeRing = 64;        // entries of wf_shade<SIMPLE>'s per-wave ring of parked specular-lobe paths
 constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)
@@ -343,7 +352,7 @@ constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot
 // as a run-time branch the extra live state cost the kernel 6 VGPRs and 3 % on EVERY bounce.
 // TL: 0 flat tree, 1 two-level structure with ForceOpaque instances only, 2 two-level with non-opaque instances (candidate re-trace compiled in)
 template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, int TL = 0, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? 4 : 5))) void wf_extend(WfArgs a, uint32_t parity)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? HRT_X_TL : (LDS_BVH ? 6 : HRT_X_EXT)))) void wf_extend(WfArgs a, uint32_t parity)
 {
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
     static_assert(!PRIMARY || !ANYHIT, "primary rays are closest-hit rays");
@@ -710,7 +719,7 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 // seeds 1 and 10: every miss pixel ~10 % off) -- the second time a forced register budget broke exactly this code in a general variant
 // (DESIGN.md section 4), so the setting is treated as a compiler hazard, not a tuning knob.
 template <int MAXL, bool SIMPLE, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MAXL != 1 || SIMPLE) ? 4 : 3, (MAXL != 1 || SIMPLE) ? 4 : 3))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SIMPLE ? HRT_X_SIMPLE : (MAXL != 1 ? 4 : 3), SIMPLE ? HRT_X_SIMPLE : (MAXL != 1 ? 4 : 3)))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     static_assert(!PRIMARY || SIMPLE, "no raygen pass: SIMPLE scenes only");
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
