@@ -330,15 +330,15 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // Persistent while-while traversal with lane refill: a wave keeps up to 64 rays of its segment in flight; whenever
 // at least kRefillMin lanes have finished their ray, they fetch the next rays of the segment (ballot + prefix rank),
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
-#ifndef HRT_X_TL
-#define HRT_X_TL 4
-#endif
-#ifndef HRT_X_EXT
-#define HRT_X_EXT 5
-#endif
-#ifndef HRT_X_SIMPLE
-#define HRT_X_SIMPLE 4
-#endif
+// Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu; measured on MI355X, built without the SLP vectoriser -- csrc/Makefile):
+//   wf_extend, tree in LDS      6   80 VGPRs without spills; the <PRIMARY> instantiation gives up 10 registers for it (-1.5 %)
+//   wf_extend, tree in global   5   6 costs +2 % (spills); 84 VGPRs
+//   wf_extend<TL>               5   100-117 VGPRs: a few spilled registers buy the fifth wave (-4 %); with the SLP vectoriser on the same
+//                                   setting doubled the kernel's time (128 VGPRs wanted)
+//   wf_shade, any variant       4   general single-light variant: 129 VGPRs wanted, -14 % against 3 waves. The same setting produced wrong sky
+//                                   radiance while the SLP vectoriser was on (138 VGPRs wanted; DESIGN 4 "compiler findings"): re-check the random
+//                                   trait scenes (scripts/parity_campaign.sh) whenever this kernel or the compiler changes. 5 on <SIMPLE>: no gain
+constexpr int kWavesExtendLds = 6, kWavesExtendGlobal = 5, kWavesExtendTwoLevel = 5, kWavesShade = 4;
 constexpr uint32_t kRefillMinDefault = 12;
 constexpr uint32_t kShadeRing = 64;        // entries of wf_shade<SIMPLE>'s per-wave ring of parked specular-lobe paths
 constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)
@@ -352,7 +352,7 @@ constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot
 // as a run-time branch the extra live state cost the kernel 6 VGPRs and 3 % on EVERY bounce.
 // TL: 0 flat tree, 1 two-level structure with ForceOpaque instances only, 2 two-level with non-opaque instances (candidate re-trace compiled in)
 template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, int TL = 0, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? HRT_X_TL : (LDS_BVH ? 6 : HRT_X_EXT)))) void wf_extend(WfArgs a, uint32_t parity)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWavesExtendTwoLevel : (LDS_BVH ? kWavesExtendLds : kWavesExtendGlobal)))) void wf_extend(WfArgs a, uint32_t parity)
 {
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
     static_assert(!PRIMARY || !ANYHIT, "primary rays are closest-hit rays");
@@ -713,13 +713,13 @@ struct NeeBuf { float ux[MAXL], uy[MAXL]; uint32_t light[MAXL]; };
 // sample at all, which the compaction needs), and -- for the lanes that have one -- again from the saved RNG state, writing the samples
 // straight into the entry's slots instead of buffering them per lane (AccumulateDirectLighting loops over all m_LightCount lights,
 // CommonLighting.hlsli:877-908; the reference's UI does not bound them).
-// Waves per SIMD: 4 for the SIMPLE variant (128 VGPRs with 13 spilled dwords; its ring of parked paths is 64 entries so that four blocks fit a
-// CU's LDS: -11 % shade time on config 2 against 3 waves with a 128-entry ring) and for the many-light variants; the general single-light variant
-// stays at 3: at 4 it is 7 % faster on config 4 and computes a WRONG sky radiance (tests/test_parity_gpu.py::test_random_material_subsets...
-// seeds 1 and 10: every miss pixel ~10 % off) -- the second time a forced register budget broke exactly this code in a general variant
-// (DESIGN.md section 4), so the setting is treated as a compiler hazard, not a tuning knob.
+// Waves per SIMD: 4 for every variant (kWavesShade above). The SIMPLE variant's ring of parked paths is 64 entries so that four blocks fit a
+// CU's LDS (-11 % shade time on config 2 against 3 waves with a 128-entry ring). The general single-light variant wants 129 VGPRs and runs
+// 14 % faster on config 4 than at 3 waves. History: while the library was built with the SLP vectoriser this variant wanted 138 VGPRs, and forced
+// to 128 it computed a WRONG sky radiance (tests/test_parity_gpu.py::test_random_material_subsets... seeds 1 and 10: every miss pixel ~10 % off;
+// DESIGN.md section 4) -- the random trait scenes are the guard for this setting.
 template <int MAXL, bool SIMPLE, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SIMPLE ? HRT_X_SIMPLE : (MAXL != 1 ? 4 : 3), SIMPLE ? HRT_X_SIMPLE : (MAXL != 1 ? 4 : 3)))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWavesShade, kWavesShade))) void wf_shade(WfArgs a, HrptPathTracerConstants cb, uint32_t parity, int bounce, int lastBounce)
 {
     static_assert(!PRIMARY || SIMPLE, "no raygen pass: SIMPLE scenes only");
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
