@@ -557,7 +557,7 @@ struct WfTraceArgs {
 };
 constexpr uint32_t kTraceChunkShift = 8;
 template <bool LDS_BVH, int DEPTH, int W, bool SHADOW, bool TL = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : (TL ? 4 : 5)))) void wf_trace_rays(WfTraceArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : (TL ? kWavesExtendTwoLevel : (LDS_BVH ? kWavesExtendLds : kWavesExtendGlobal))))) void wf_trace_rays(WfTraceArgs a)
 {
     static_assert(!TL || (!LDS_BVH && W == 4), "two-level structure: global 4-wide trees (every instance opaque: a shadow ray ends at its first hit)");
     extern __shared__ __attribute__((aligned(128))) char smem[];
