@@ -252,7 +252,7 @@ bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& err
         if ((uint64_t)md.m_IndexOffsets[0] + md.m_IndexCounts[0] > s.indexCount || md.m_IndexCounts[0] % 3 != 0) { error = "mesh LOD0 index range invalid"; return false; }
         triCount += md.m_IndexCounts[0] / 3;
     }
-    if (flatLimit && triCount >= (1ull << 29)) { error = "too many triangles"; return false; }
+    if (flatLimit && triCount >= kMaxStructureTriangles) { error = "too many triangles for the flat structure (2^32 / 48)"; return false; }
     return true;
 }
 
@@ -403,7 +403,7 @@ bool build_mesh_trees(const HrptSceneDesc& s, BuiltTwoLevel& out, std::vector<in
         Box root;
         const int32_t r = b.build(0, nt, 0, root);
         const uint32_t triBase = (uint32_t)out.tris.size(), nodeBase = (uint32_t)out.nodes4.size();
-        if ((uint64_t)triBase + nt >= (1ull << 29)) { error = "too many distinct triangles for the two-level structure"; return false; }
+        if ((uint64_t)triBase + nt >= kMaxStructureTriangles) { error = "too many distinct triangles for the two-level structure (2^32 / 48)"; return false; }
         auto fix_leaf = [&](int32_t ref) { const uint32_t enc = (uint32_t)~ref; return ~(int32_t)((((enc >> 2) + triBase) << 2) | (enc & 3u)); };
         if (r < 0) meshRoot[m] = fix_leaf(r);
         else {
@@ -520,7 +520,7 @@ bool build_scene_two_level(const HrptSceneDesc& s, BuiltTwoLevel& out, std::stri
     out = BuiltTwoLevel();
     uint64_t triCount = 0;
     if (!validate_scene(s, triCount, error, false)) return false;
-    if (s.instanceCount >= (1u << 29)) { error = "too many instances for the two-level structure"; return false; }
+    if (s.instanceCount >= kMaxStructureNodes) { error = "too many instances for the two-level structure (2^25)"; return false; }
     std::vector<int32_t> meshRoot;
     if (!build_mesh_trees(s, out, meshRoot, error)) return false;
     // seed instance records so that rebuild_two_level_instances finds the mesh roots

@@ -127,7 +127,10 @@ constexpr uint32_t kTraversalStackDepth = 64;   // 2-wide trees: the builders gu
 constexpr uint32_t kHostBuilderDepthGoal = 32;  // the host SAH builder switches to median splits early enough to stay below this
 
 // Validates every index / range of the scene description (false + message); triCount = world triangles over all instances.
-// (flatLimit: the flat tree's leaf references hold triangle indices below 2^29; the two-level structure only limits DISTINCT triangles)
+// (flatLimit: the traversal kernels address nodes and triangle records by 32-bit byte offsets from the array base (pt_device.h GlobalBvh4), so one
+// structure holds fewer than 2^32 / 48 triangle records and 2^25 nodes of 128 bytes (checked after the build: a 4-wide tree over N triangles
+// has between N / 12 and N nodes); the two-level structure only counts DISTINCT triangles, and instances as leaves of its upper tree)
+constexpr uint64_t kMaxStructureTriangles = 0xFFFFFFFFull / 48ull, kMaxStructureNodes = 1ull << 25;
 bool validate_scene(const HrptSceneDesc& scene, uint64_t& triCount, std::string& error, bool flatLimit = true);
 void build_instance_shade(const HrptSceneDesc& scene, std::vector<HostInstShade>& out);
 bool scene_needs_tangents(const HrptSceneDesc& scene);

@@ -242,6 +242,7 @@ static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v,
         }
     }
     const HostNode4* dn4; const HostInstance* di; const HostInstShade* dis;
+    if (b.nodes4.size() >= kMaxStructureNodes) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: more than 2^25 nodes (32-bit node offsets in the traversal kernels)");
     if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instances.data(), b.instances.size(), &di, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instShade.data(), b.instShade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
@@ -281,7 +282,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
         firstBuild = true;
     }
     v.instances = nullptr; v.instanceCount = 0; c->traits.twoLevelStackNeed = 0;
-    if (sceneTris >= (1ull << 29)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: too many triangles for the flat structure (2^29; instanced scenes of opaque materials can use HRPT_ACCEL_TWO_LEVEL)");
+    if (sceneTris >= kMaxStructureTriangles) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: too many triangles for the flat structure (2^32 / 48 = 89 M world-space triangles; instanced scenes can use HRPT_ACCEL_TWO_LEVEL)");
     uint32_t maxDepth = 0, maxDepth4 = 0;
     bool built = false;
     const int builder = c->bvhBuilder == HRPT_BVH_BUILDER_AUTO ? (sceneTris >= 65536 ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_HOST_SAH) : c->bvhBuilder;
@@ -351,6 +352,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
         maxDepth = bvh.maxDepth; maxDepth4 = bvh.maxDepth4;
         c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.sahCost = bvh.sahCost;
     }
+    if (v.node4Count >= kMaxStructureNodes) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: more than 2^25 nodes (32-bit node offsets in the traversal kernels)");
     c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = v.nodeCount; c->buildInfo.node4Count = v.node4Count;
     c->buildInfo.maxDepth = maxDepth; c->buildInfo.maxDepth4 = maxDepth4;

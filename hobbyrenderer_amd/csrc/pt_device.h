@@ -203,15 +203,17 @@ struct GlobalBvh {
 struct GlobalBvh4 {
     static constexpr int kWidth = 4; static constexpr bool kTwoLevel = false;
     const GpuNode4* nodes; const GpuTri* tris;
+    // Nodes and triangles are addressed as (array base, 32-bit byte offset): the base stays in scalar registers and a lane holds one VGPR per
+    // address instead of a pair (global_load saddr + voffset form; 64-bit address arithmetic is two VALU operations per add on gfx950).
+    // Hence the flat structure's limits: fewer than 2^25 4-wide nodes and 2^32 / 48 triangles (bvh_build.cpp validate_scene).
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
     {
-        const float4* p = reinterpret_cast<const float4*>(tris + i);
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (size_t)(i * 48u));
         a = p[0]; b = p[1]; c = p[2];
     }
     // one 16-byte row of node i: byte offset 0/16 = min/max x of the four children, 32/48 = y, 64/80 = z, 96 = child refs
-    HRT_DEV const char* rowptr(int i, uint32_t byteOffset) const { return reinterpret_cast<const char*>(nodes) + ((size_t)(uint32_t)i * 128u + byteOffset); }
-    HRT_DEV float4 row(int i, uint32_t byteOffset) const { return *reinterpret_cast<const float4*>(rowptr(i, byteOffset)); }
-    static HRT_DEV const char* flip16(const char* p) { return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(p) ^ (uintptr_t)16); }
+    HRT_DEV uint32_t rowoff(int i, uint32_t byteOffset) const { return (uint32_t)i * 128u + byteOffset; }
+    HRT_DEV float4 load(uint32_t off) const { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (size_t)off); }
 };
 
 // Conservative slab test of one child box against [t0, t1]. Culling only: it never changes which hit is
@@ -278,11 +280,10 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 noiF, f3 inv,
         const uint32_t nx = inv.x < 0.0f ? 16u : 0u, ny = inv.y < 0.0f ? 48u : 32u, nz = inv.z < 0.0f ? 80u : 64u;
         // (the far address is derived from the NEAR ADDRESS, not from the offset: offsets are loop-invariant per ray and the compiler
         // would otherwise keep all six in registers -- +6 VGPRs cost the kernel a wave of occupancy; nodes are 128-byte aligned)
-        const char* const pnx = bvh.rowptr(cur, nx); const char* const pny = bvh.rowptr(cur, ny); const char* const pnz = bvh.rowptr(cur, nz);
-        const float4 anx = *reinterpret_cast<const float4*>(pnx), any = *reinterpret_cast<const float4*>(pny), anz = *reinterpret_cast<const float4*>(pnz);
-        const float4 afx = *reinterpret_cast<const float4*>(BVH::flip16(pnx)), afy = *reinterpret_cast<const float4*>(BVH::flip16(pny)),
-                     afz = *reinterpret_cast<const float4*>(BVH::flip16(pnz));
-        const float4 chf = bvh.row(cur, 96u);
+        const uint32_t onx = bvh.rowoff(cur, nx), ony = bvh.rowoff(cur, ny), onz = bvh.rowoff(cur, nz);
+        const float4 anx = bvh.load(onx), any = bvh.load(ony), anz = bvh.load(onz);
+        const float4 afx = bvh.load(onx ^ 16u), afy = bvh.load(ony ^ 16u), afz = bvh.load(onz ^ 16u);
+        const float4 chf = bvh.load(bvh.rowoff(cur, 96u));
         auto box = [&](float bnx, float bny, float bnz, float bfx, float bfy, float bfz) {
             const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(bnx, inv.x, noi.x), __builtin_fmaf(bny, inv.y, noi.y)), __builtin_fmaf(bnz, inv.z, noi.z)), tmin);
             const float far3 = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bfx, inv.x, noiF.x), __builtin_fmaf(bfy, inv.y, noiF.y)), __builtin_fmaf(bfz, inv.z, noiF.z));

@@ -183,15 +183,10 @@ struct LdsBvh {
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
-    HRT_DEV const char* rowptr(int i, uint32_t byteOffset) const { return reinterpret_cast<const char*>(nodes + 8 * i) + byteOffset; }
-    HRT_DEV float4 row(int i, uint32_t byteOffset) const { return *reinterpret_cast<const float4*>(rowptr(i, byteOffset)); }
-    // LDS addresses are 32-bit: flip bit 4 of the LDS offset (the copy starts 128-byte aligned: setup_lds)
-    static HRT_DEV const char* flip16(const char* p)
-    {
-        typedef __attribute__((address_space(3))) const char* LdsPtr;
-        const uint32_t o = (uint32_t)(uintptr_t)(LdsPtr)p ^ 16u;
-        return (const char*)(LdsPtr)(uintptr_t)o;
-    }
+    // rows by 32-bit LDS address (the copy starts 128-byte aligned: setup_lds, so near ^ 16 is the far row of the same axis)
+    typedef __attribute__((address_space(3))) const char* LdsPtr;
+    HRT_DEV uint32_t rowoff(int i, uint32_t byteOffset) const { return (uint32_t)(uintptr_t)(LdsPtr) reinterpret_cast<const char*>(nodes) + (uint32_t)i * 128u + byteOffset; }
+    HRT_DEV float4 load(uint32_t off) const { return *reinterpret_cast<const float4*>((const char*)(LdsPtr)(uintptr_t)off); }
 };
 template <int W> struct GlobalBvhOf;
 template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV GlobalBvh make(const SceneView& s) { GlobalBvh g; g.nodes = s.nodes; g.tris = s.tris; return g; } };
@@ -332,13 +327,13 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 // so the traversal loop runs with full lanes instead of waiting for the slowest ray of a 64-ray batch.
 // Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu; measured on MI355X, built without the SLP vectoriser -- csrc/Makefile):
 //   wf_extend, tree in LDS      6   80 VGPRs without spills; the <PRIMARY> instantiation gives up 10 registers for it (-1.5 %)
-//   wf_extend, tree in global   5   6 costs +2 % (spills); 84 VGPRs
+//   wf_extend, tree in global   6   80-82 VGPRs since nodes and triangles are addressed by 32-bit offsets (84 and +2 % at 6 waves before): config 4 -2 %
 //   wf_extend<TL>               5   100-117 VGPRs: a few spilled registers buy the fifth wave (-4 %); with the SLP vectoriser on the same
 //                                   setting doubled the kernel's time (128 VGPRs wanted)
 //   wf_shade, any variant       4   general single-light variant: 129 VGPRs wanted, -14 % against 3 waves. The same setting produced wrong sky
 //                                   radiance while the SLP vectoriser was on (138 VGPRs wanted; DESIGN 4 "compiler findings"): re-check the random
 //                                   trait scenes (scripts/parity_campaign.sh) whenever this kernel or the compiler changes. 5 on <SIMPLE>: no gain
-constexpr int kWavesExtendLds = 6, kWavesExtendGlobal = 5, kWavesExtendTwoLevel = 5, kWavesShade = 4;
+constexpr int kWavesExtendLds = 6, kWavesExtendGlobal = 6, kWavesExtendTwoLevel = 5, kWavesShade = 4;
 constexpr uint32_t kRefillMinDefault = 12;
 constexpr uint32_t kShadeRing = 64;        // entries of wf_shade<SIMPLE>'s per-wave ring of parked specular-lobe paths
 constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)

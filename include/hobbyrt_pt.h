@@ -279,7 +279,10 @@ int  hrpt_create(const HrptDeviceDesc* desc, HrptContext** out);
 void hrpt_destroy(HrptContext* ctx);
 const char* hrpt_last_error(const HrptContext* ctx);      /* ctx may be NULL: last creation error */
 
-/* Replaces scene buffer upload + BLAS/TLAS build. Validates every index in the scene data. */
+/* Replaces scene buffer upload + BLAS/TLAS build. Validates every index in the scene data.
+ * Size limit: one acceleration structure holds fewer than 2^32 / 48 (89 M) triangle records -- world-space triangles (instances x mesh triangles)
+ * for the flat structure, distinct mesh triangles for the two-level one (hrpt_set_acceleration_structure) -- and fewer than 2^25 tree nodes,
+ * because the traversal kernels address both arrays by 32-bit byte offsets; larger scenes fail with HRPT_ERR_INVALID_ARGUMENT. */
 int  hrpt_upload_scene(HrptContext* ctx, const HrptSceneDesc* scene);
 
 /* (Re)allocates the RGBA32F Accumulation (u1) and Output (u0) images, PathTracerRenderer::Setup :14-29. */
