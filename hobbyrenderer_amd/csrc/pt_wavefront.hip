@@ -1043,13 +1043,14 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
 //   the recorded candidate lists (its stack serves the rare re-trace behind an overflowing list) and evaluates the contributions.
 // MODE kShadowSlim: kShadowOpaque with directional lights only and the 32-byte entries of wf_shade<1, SIMPLE> (see there).
 enum : int { kShadowOpaque = 0, kShadowBuffered = 1, kShadowResolve = 2, kShadowSlim = 3 };
-// (the buffered variant is held at 3 waves per SIMD: the gradient-sampled alpha test of mip-mapped MASK textures -- a rare path -- would
-// otherwise raise its register count past 170 and cost every scene with alpha-tested geometry a wave of occupancy; the resolve variant as
-// well: 185 -> 168 VGPRs, glass config shadow stage -6 %. Checked with 600 + 150 random trait scenes under HRPT_WF_SHADOW_PATH=2, because a
-// forced register budget has broken wf_shade's general variant twice; the two-level variants too: 183..248 -> 168 VGPRs, scenes with non-opaque
-// instances -16 % shadow time, 300 random two-level scenes against the flat structure)
+// Waves per SIMD (built without the SLP vectoriser, csrc/Makefile): the buffered variant is held at 3 -- the gradient-sampled alpha test of
+// mip-mapped MASK textures, a rare path, would otherwise cost every scene with alpha-tested geometry a wave (145-152 VGPRs; at 4 waves config 4's
+// shadow stage is 6 % SLOWER: it traverses, and spills hurt its loops); the resolve variant runs at 4 (146-150 VGPRs wanted, 128 given: it waits
+// on its queue reads for 71 % of its cycles and only walks candidate lists: glass config shadow stage -6 %); the two-level variants at 3
+// (scenes with non-opaque instances -16 % shadow time). Forced budgets are re-checked with the random trait scenes (scripts/parity_campaign.sh:
+// HRPT_WF_SHADOW_PATH=1 / 2 and the two-level scenes), because one has broken wf_shade's general variant before.
 template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, int TL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == 1 || MODE == 2 || TL != 0) ? 3 : 1))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 2 && TL == 0 ? 4 : ((MODE == 1 || TL != 0) ? 3 : 1)))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     static_assert(!TL || (!LDS_BVH && W == 4 && (MODE == kShadowOpaque || MODE == kShadowSlim)), "two-level structure: opaque any-hit query over the global tree");
     constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;

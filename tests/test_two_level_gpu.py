@@ -148,6 +148,28 @@ def test_4096_instances_of_a_25k_triangle_mesh(luts):
     assert i_flat.triangleCount > 60_000_000 and i_two.triangleCount < 30_000 and i_two.distinctMeshes == 3
 
 
+def test_scene_beyond_the_flat_structure_limit(luts):
+    """include/hobbyrt_pt.h, hrpt_upload_scene: one structure holds fewer than 2^32 / 48 triangle records (32-bit byte offsets in the traversal
+    kernels). 6 400 instances of meshes of up to 25 k triangles are 109 M world triangles: the flat structure refuses them (before allocating
+    anything), the two-level structure holds the 26 k distinct ones, and AUTO picks it."""
+    from hobbyrenderer_amd.native import PathTracerContext, HrptError
+    n = 80
+    sc = instanced_scene(luts, n, seed=6, sphere_res=(160, 80))
+    view, pos = _camera(240, 136, n)
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(S.ACCEL_FLAT)
+        with pytest.raises(HrptError, match="flat structure"):
+            c.upload_scene(sc)
+    finally:
+        c.close()
+    a_two, n_two, i_two, fb = _render(luts, sc, S.ACCEL_TWO_LEVEL, 240, 136, 1, 2, view, pos)
+    a_auto, n_auto, i_auto, _ = _render(luts, sc, S.ACCEL_AUTO, 240, 136, 1, 2, view, pos)
+    assert i_two.structure == S.ACCEL_TWO_LEVEL and i_auto.structure == S.ACCEL_TWO_LEVEL and fb == 0
+    assert i_two.triangleCount < 30000 and n_two == n_auto and n_two[0] > 0
+    assert np.array_equal(a_two.view(np.uint32), a_auto.view(np.uint32)) and np.isfinite(a_two).all() and a_two[..., :3].max() > 0
+
+
 def test_two_level_update_instances_rebuilds_only_the_instance_tree(luts):
     n = 12
     sc = instanced_scene(luts, n, seed=9)
