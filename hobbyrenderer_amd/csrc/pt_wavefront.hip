@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
     typename GlobalBvhOf<(TL ? kTwoLevelTree : W)>::type gbvh = GlobalBvhOf<(TL ? kTwoLevelTree : W)>::make(a.scene);
     const SceneView& s = a.scene;
 
-    const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
+    const uint32_t wavesPerBlock = kBlock / 64;
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     const float4* __restrict__ rayO = ANYHIT ? a.b.sqO : a.b.rayO[parity];
     float4* __restrict__ rayD = ANYHIT ? a.b.sqD : a.b.rayD[parity];
