@@ -149,6 +149,7 @@ int hrpt_create(const HrptDeviceDesc* desc, HrptContext** out)
     c->ownStream = c->stream;
     if (const char* e = getenv("HRPT_WF_SEGMENT_SHIFT")) c->wf.segmentShift = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BLOCKS_PER_CU")) c->wf.blocksPerCu = (uint32_t)atoi(e);
+    if (const char* e = getenv("HRPT_WF_EXTEND_BLOCKS_PER_CU")) c->wf.extendBlocksPerCu = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_REFILL_MIN")) c->wf.refillMin = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_WF_BVH_WIDTH")) c->wf.bvhWidth = (uint32_t)atoi(e);
     if (const char* e = getenv("HRPT_BVH_BUILDER")) c->bvhBuilder = (strcmp(e, "ploc") == 0 || strcmp(e, "2") == 0) ? HRPT_BVH_BUILDER_GPU_PLOC : ((strcmp(e, "gpu") == 0 || strcmp(e, "lbvh") == 0 || strcmp(e, "1") == 0) ? HRPT_BVH_BUILDER_GPU_LBVH : ((strcmp(e, "auto") == 0 || strcmp(e, "3") == 0) ? HRPT_BVH_BUILDER_AUTO : HRPT_BVH_BUILDER_HOST_SAH));

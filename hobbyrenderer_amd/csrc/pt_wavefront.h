@@ -47,6 +47,7 @@ struct WavefrontState {
     // tuning knobs (0 = default)
     uint64_t maxSamplesPerBatch = 0;
     uint32_t blocksPerCu = 0;
+    uint32_t extendBlocksPerCu = 0;    // HRPT_WF_EXTEND_BLOCKS_PER_CU: grid of wf_extend alone (0 = automatic: 12 / 6 per CU for a tree in LDS / global memory)
     bool profile = false;              // record HIP events around every extend / shade / shadow launch (HRPT_FRAME_PROFILE)
     uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic

@@ -23,6 +23,8 @@
 #define HRPT_PHASE_TU 1
 #include "pt_wavefront.h"
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "bvh_build.h"
@@ -1243,23 +1245,50 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 }
 
 // ------------------------------------------------------------------ host side
+// The persistent kernels divide their segments evenly among the waves of the grid (seg = wave, wave + waves, ...), so a grid that is not a
+// whole number of ROUNDS of what a CU holds of that kernel finishes late: with six resident blocks per CU a grid of 16 per CU takes three
+// rounds of 1/16 of the work each, 12 takes two of 1/12 (measured: LDS-tree wf_extend +8 % at 16, global-tree wf_extend +20 % at 7 against 6).
+// launch_rounds trims the requested grid to whole rounds of the kernel's own occupancy (hipOccupancyMaxActiveBlocksPerMultiprocessor: its
+// registers, its LDS bytes), asked once per kernel and LDS size.
+static thread_local uint32_t tlCus = 0;        // compute units of the device the calling thread launches on (wavefront_render / wavefront_trace_rays set it)
+static int resident_blocks_per_cu(const void* kernel, size_t ldsBytes)
+{
+    static std::mutex mu; static std::unordered_map<uint64_t, int> cache;
+    const uint64_t key = (uint64_t)(uintptr_t)kernel * 0x9E3779B97F4A7C15ull ^ (uint64_t)ldsBytes;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)kBlock, ldsBytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    cache.emplace(key, n);
+    return n;
+}
+template <class K, class... Args> static void launch_rounds(K kernel, dim3 g, size_t ldsBytes, hipStream_t st, Args... args)
+{
+    const int resident = tlCus ? resident_blocks_per_cu(reinterpret_cast<const void*>(kernel), ldsBytes) : 0;
+    const uint32_t perRound = tlCus * (uint32_t)(resident > 0 ? resident : 0);
+    if (perRound && g.x > perRound) g.x = (g.x / perRound) * perRound;
+    hipLaunchKernelGGL(kernel, g, dim3(kBlock), ldsBytes, st, args...);
+}
 struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; bool twoLevelCandidates = false; };
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
-    if constexpr (W == 4) if (a.primary && !anyHit) { hipLaunchKernelGGL((wf_extend<L, D, W, false, false, true>), g, dim3(kBlock), sh, st, a, parity); return; }
-    if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
-    else hipLaunchKernelGGL((wf_extend<L, D, W, false>), g, dim3(kBlock), sh, st, a, parity);
+    if constexpr (W == 4) if (a.primary && !anyHit) { launch_rounds((wf_extend<L, D, W, false, false, true>), g, sh, st, a, parity); return; }
+    if (anyHit) launch_rounds((wf_extend<L, D, W, true>), g, sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
+    else launch_rounds((wf_extend<L, D, W, false>), g, sh, st, a, parity);
 }
 // nonOpaque: 0 = opaque scene, 1 = buffered query inside wf_shadow, 2 = resolve only (after the any-hit pass)
 template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
-    if (nonOpaque == kShadowResolve) hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowResolve>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    if (nonOpaque == kShadowResolve) launch_rounds((wf_shadow<L, D, W, false, kShadowResolve>), g, sh, st, a, cb, bounce);
     else if (nonOpaque == kShadowBuffered) {   // general variant (all light types) + candidate buffer
+        // (not trimmed to whole rounds: measured, the buffered variant -- three resident blocks per CU, long uneven entries -- is 3 % slower
+        // with 15 or 6 blocks per CU than with the 16 or 8 asked for)
         hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowBuffered>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
-    } else if (nonOpaque == kShadowSlim) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowSlim>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    } else if (nonOpaque == kShadowSlim) launch_rounds((wf_shadow<L, D, W, true, kShadowSlim>), g, sh, st, a, cb, bounce);
+    else if (dirOnly) launch_rounds((wf_shadow<L, D, W, true, kShadowOpaque>), g, sh, st, a, cb, bounce);
+    else launch_rounds((wf_shadow<L, D, W, false, kShadowOpaque>), g, sh, st, a, cb, bounce);
 }
 
 // stack need classes: BVH2 8/16/32/64 (maxDepth + 2), BVH4 16/32/64 (3 * maxDepth4 + 2); class 64 = "deeper than the LDS part": the kernel keeps
@@ -1283,14 +1312,14 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
 template <int D, int TL> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
 {
     if (TL == 2) sh += (size_t)kTwoLevelCandidates * 3 * kBlock * 4;      // candidate columns of the buffered two-level shadow query
-    if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
-    else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    if (mode == kShadowSlim) launch_rounds((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, sh, st, a, cb, bounce);
+    else if (dirOnly) launch_rounds((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, sh, st, a, cb, bounce);
+    else launch_rounds((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, sh, st, a, cb, bounce);
 }
 template <int D, int TL> void launch_extend_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
 {
-    if (a.primary) hipLaunchKernelGGL((wf_extend<false, D, 4, false, TL, true>), g, dim3(kBlock), sh, st, a, parity);
-    else hipLaunchKernelGGL((wf_extend<false, D, 4, false, TL, false>), g, dim3(kBlock), sh, st, a, parity);
+    if (a.primary) launch_rounds((wf_extend<false, D, 4, false, TL, true>), g, sh, st, a, parity);
+    else launch_rounds((wf_extend<false, D, 4, false, TL, false>), g, sh, st, a, parity);
 }
 void launch_extend(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit = false)
 {
@@ -1322,7 +1351,7 @@ void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
 namespace {
 template <bool L, int D, bool SH> void launch_trace_rays_t(dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
 {
-    hipLaunchKernelGGL((wf_trace_rays<L, D, 4, SH>), g, dim3(kBlock), lds + (SH ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0), st, a);
+    launch_rounds((wf_trace_rays<L, D, 4, SH>), g, lds + (SH ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0), st, a);
 }
 template <bool L, bool SH> void launch_trace_rays_d(int depth, dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
 {
@@ -1341,6 +1370,7 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     hipError_t e; int dev = 0; hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    tlCus = cus;
     const bool twoLevel = traits.twoLevelStackNeed != 0;
     const uint32_t need = twoLevel ? traits.twoLevelStackNeed : 3 * traits.bvh4MaxDepth + 2;
     const int depth = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
@@ -1368,9 +1398,9 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     }
     const size_t ldsBytes = stackBytes + (lds ? bvhBytes : 0);
     if (twoLevel) {
-        const dim3 g(grid), b(kBlock); const size_t sl = ldsBytes;     // (no candidate columns: every instance is opaque)
-        if (shadow) { if (depth <= 16) hipLaunchKernelGGL((wf_trace_rays<false, 16, 4, true, true>), g, b, sl, stream, a); else if (depth <= 32) hipLaunchKernelGGL((wf_trace_rays<false, 32, 4, true, true>), g, b, sl, stream, a); else hipLaunchKernelGGL((wf_trace_rays<false, 64, 4, true, true>), g, b, sl, stream, a); }
-        else { if (depth <= 16) hipLaunchKernelGGL((wf_trace_rays<false, 16, 4, false, true>), g, b, sl, stream, a); else if (depth <= 32) hipLaunchKernelGGL((wf_trace_rays<false, 32, 4, false, true>), g, b, sl, stream, a); else hipLaunchKernelGGL((wf_trace_rays<false, 64, 4, false, true>), g, b, sl, stream, a); }
+        const dim3 g(grid); const size_t sl = ldsBytes;     // (no candidate columns: every instance is opaque)
+        if (shadow) { if (depth <= 16) launch_rounds((wf_trace_rays<false, 16, 4, true, true>), g, sl, stream, a); else if (depth <= 32) launch_rounds((wf_trace_rays<false, 32, 4, true, true>), g, sl, stream, a); else launch_rounds((wf_trace_rays<false, 64, 4, true, true>), g, sl, stream, a); }
+        else { if (depth <= 16) launch_rounds((wf_trace_rays<false, 16, 4, false, true>), g, sl, stream, a); else if (depth <= 32) launch_rounds((wf_trace_rays<false, 32, 4, false, true>), g, sl, stream, a); else launch_rounds((wf_trace_rays<false, 64, 4, false, true>), g, sl, stream, a); }
     } else
     if (lds) { if (shadow) launch_trace_rays_d<true, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<true, false>(depth, dim3(grid), ldsBytes, stream, a); }
     else { if (shadow) launch_trace_rays_d<false, true>(depth, dim3(grid), ldsBytes, stream, a); else launch_trace_rays_d<false, false>(depth, dim3(grid), ldsBytes, stream, a); }
@@ -1560,6 +1590,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     int dev = 0; hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { error = "hipGetDeviceProperties"; return e; }
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    tlCus = cus;
     // Node width per kernel class (measured, scripts/gpu_bvh4_ab.sh): the 4-wide tree wins for closest-hit queries everywhere
     // (fewer, fuller steps: -9..-11% extend time on configs 2/4/5) and for shadow queries that buffer non-opaque candidates or
     // read the BVH from global memory (-9..-14%); the small opaque any-hit kernel over an LDS-resident BVH is faster 2-wide
@@ -1616,11 +1647,17 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // two-frames-in-flight loop (hrpt_set_shadow_overlap(ctx, 0)) and traverses a tree in global memory does better with half the grid:
     // its latency-bound kernels leave room for the other lane's (config 4 14.4 -> 14.0 ms, config 5 22.6 -> 21.9 ms per frame).
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : ((st.serialShadow && !vE.lds) ? 8 : 16);
+    // wf_extend gets a grid of its own: a whole number of rounds of the six blocks a CU holds of it. Measured (scripts/env_sweep.sh
+    // HRPT_WF_EXTEND_BLOCKS_PER_CU): tree in LDS 12 per CU (two rounds; 16 = 2.67 rounds: +8 % on config 2, the last round runs with four of six
+    // slots filled), tree in global memory 6 (one persistent round: its waves are latency-bound and every further round re-pays the ramp:
+    // config 4 extend -6 %, glass config -20 %). The two-level kernels keep the general grid.
+    const uint32_t extendBlocksPerCu = st.extendBlocksPerCu ? st.extendBlocksPerCu : (st.blocksPerCu ? st.blocksPerCu : (vE.twoLevel ? blocksPerCu : (vE.lds ? 12u : 6u)));
+    const uint32_t maxBlocksPerCu = blocksPerCu > extendBlocksPerCu ? blocksPerCu : extendBlocksPerCu;
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
         // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part
         const uint32_t worst = traits.twoLevelStackNeed ? traits.twoLevelStackNeed : (vE.width == 4 || vS.width == 4 ? 3 * traits.bvh4MaxDepth + 2 : traits.bvhMaxDepth + 2);
         const uint32_t entries = worst > (uint32_t)kExtendLdsStack ? worst - kExtendLdsStack : 1u;
-        const size_t threads = (size_t)cus * blocksPerCu * kBlock, bytes = 2 * threads * entries * 4;
+        const size_t threads = (size_t)cus * maxBlocksPerCu * kBlock, bytes = 2 * threads * entries * 4;
         if (bytes > st.spillBytes) {
             if (st.spill) { (void)hipStreamSynchronize(stream); if (st.auxStream) (void)hipStreamSynchronize(st.auxStream); (void)hipFree(st.spill); st.spill = nullptr; st.spillBytes = 0; }
             if ((e = hipMalloc(&st.spill, bytes)) != hipSuccess) { error = "hipMalloc(traversal stack overflow)"; return e; }
@@ -1649,6 +1686,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         a.numSegments = (a.numSamples + (1u << shift) - 1) >> shift;
         const uint32_t wavesNeeded = a.numSegments, blocksNeeded = (wavesNeeded + 3) / 4;
         uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = blocksNeeded; if (grid == 0) grid = 1;
+        uint32_t gridExtend = cus * extendBlocksPerCu; if (gridExtend > blocksNeeded) gridExtend = blocksNeeded; if (gridExtend == 0) gridExtend = 1;
 
         HrptPathTracerConstants cb = constants;
         cb.m_AccumulationIndex = constants.m_AccumulationIndex + first;
@@ -1676,7 +1714,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const bool timedEnds = st.profile && st.eventsUsed + 4 <= 4096;
         if (!fusedPrimary) {
             if (timedEnds) timing_mark(st, stream, 3, true);
-            hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
+            launch_rounds(wf_raygen, dim3(grid), 0, stream, a, cb, jt);
             if (timedEnds) timing_mark(st, stream, 3, false);
         }
         {   // raygen: sampleRadiance zeroed + one path record per pixel of the rectangle and index; resolve: sampleRadiance read, Accumulation
@@ -1705,8 +1743,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         auto shadow_stage = [&](hipStream_t sst, int bounce) {
             a.shadowParity = (uint32_t)bounce & 1u;
             if (shadowMode == kShadowResolve) {
-                if (traits.directionalLightsOnly) hipLaunchKernelGGL((wf_shadow_rays<true>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
-                else hipLaunchKernelGGL((wf_shadow_rays<false>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
+                if (traits.directionalLightsOnly) launch_rounds((wf_shadow_rays<true>), dim3(grid), 0, sst, a, cb);
+                else launch_rounds((wf_shadow_rays<false>), dim3(grid), 0, sst, a, cb);
                 launch_extend(vA, dim3(grid), vA.ldsBytes, sst, a, 0u, true);
             }
             launch_shadow(vS, dim3(grid), vS.ldsBytes, sst, a, cb, bounce, traits.directionalLightsOnly, shadowMode);
@@ -1717,16 +1755,16 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             const bool timed = st.profile && st.eventsUsed + 8 <= 4096;
             if (timed) timing_mark(st, stream, 0, true);
             a.primary = (fusedPrimary && bounce == 0) ? 1u : 0u;
-            launch_extend(vE, dim3(grid), vE.ldsBytes, stream, a, parity);
+            launch_extend(vE, dim3(gridExtend), vE.ldsBytes, stream, a, parity);
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
-            if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
-            else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
-            else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
-            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
-            else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
+            if (maxLights > kMaxLights) launch_rounds((wf_shade<0, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
+            else if (manyLights) launch_rounds((wf_shade<(int)kMaxLights, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
+            else if (simpleScene && a.primary) launch_rounds((wf_shade<1, true, true>), dim3(grid), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
+            else if (simpleScene) launch_rounds((wf_shade<1, true>), dim3(grid), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
+            else launch_rounds((wf_shade<1, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
                 if ((e = hipEventRecord(st.forkEvents[(size_t)bounce], stream)) != hipSuccess || (e = hipStreamWaitEvent(st.auxStream, st.forkEvents[(size_t)bounce], 0)) != hipSuccess) { error = "fork to the shadow stream"; return e; }
