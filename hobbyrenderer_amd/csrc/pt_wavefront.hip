@@ -1249,7 +1249,9 @@ __global__ __launch_bounds__(kBlock) void wf_resolve(WfArgs a, float4* __restric
 // whole number of ROUNDS of what a CU holds of that kernel finishes late: with six resident blocks per CU a grid of 16 per CU takes three
 // rounds of 1/16 of the work each, 12 takes two of 1/12 (measured: LDS-tree wf_extend +8 % at 16, global-tree wf_extend +20 % at 7 against 6).
 // launch_rounds trims the requested grid to whole rounds of the kernel's own occupancy (hipOccupancyMaxActiveBlocksPerMultiprocessor: its
-// registers, its LDS bytes), asked once per kernel and LDS size.
+// registers, its LDS bytes), asked once per kernel and LDS size. Used for the closest-hit traversal kernels (wf_extend, wf_trace_rays), where
+// the effect is large and consistent; the other kernels launch the grid asked for: trimmed, the any-hit pass of the glass config lost 12 %
+// (one round of its five resident blocks instead of eight blocks per CU) and the buffered shadow kernel 3 %, the rest did not move.
 static thread_local uint32_t tlCus = 0;        // compute units of the device the calling thread launches on (wavefront_render / wavefront_trace_rays set it)
 static int resident_blocks_per_cu(const void* kernel, size_t ldsBytes)
 {
@@ -1275,20 +1277,20 @@ struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
     if constexpr (W == 4) if (a.primary && !anyHit) { launch_rounds((wf_extend<L, D, W, false, false, true>), g, sh, st, a, parity); return; }
-    if (anyHit) launch_rounds((wf_extend<L, D, W, true>), g, sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
+    if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
     else launch_rounds((wf_extend<L, D, W, false>), g, sh, st, a, parity);
 }
 // nonOpaque: 0 = opaque scene, 1 = buffered query inside wf_shadow, 2 = resolve only (after the any-hit pass)
 template <bool L, int D, int W> void launch_shadow_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int nonOpaque)
 {
-    if (nonOpaque == kShadowResolve) launch_rounds((wf_shadow<L, D, W, false, kShadowResolve>), g, sh, st, a, cb, bounce);
+    if (nonOpaque == kShadowResolve) hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowResolve>), g, dim3(kBlock), sh, st, a, cb, bounce);
     else if (nonOpaque == kShadowBuffered) {   // general variant (all light types) + candidate buffer
         // (not trimmed to whole rounds: measured, the buffered variant -- three resident blocks per CU, long uneven entries -- is 3 % slower
         // with 15 or 6 blocks per CU than with the 16 or 8 asked for)
         hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowBuffered>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, cb, bounce);
-    } else if (nonOpaque == kShadowSlim) launch_rounds((wf_shadow<L, D, W, true, kShadowSlim>), g, sh, st, a, cb, bounce);
-    else if (dirOnly) launch_rounds((wf_shadow<L, D, W, true, kShadowOpaque>), g, sh, st, a, cb, bounce);
-    else launch_rounds((wf_shadow<L, D, W, false, kShadowOpaque>), g, sh, st, a, cb, bounce);
+    } else if (nonOpaque == kShadowSlim) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowSlim>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<L, D, W, true, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<L, D, W, false, kShadowOpaque>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 
 // stack need classes: BVH2 8/16/32/64 (maxDepth + 2), BVH4 16/32/64 (3 * maxDepth4 + 2); class 64 = "deeper than the LDS part": the kernel keeps
@@ -1312,9 +1314,9 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
 template <int D, int TL> void launch_shadow_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, const HrptPathTracerConstants& cb, int bounce, bool dirOnly, int mode)
 {
     if (TL == 2) sh += (size_t)kTwoLevelCandidates * 3 * kBlock * 4;      // candidate columns of the buffered two-level shadow query
-    if (mode == kShadowSlim) launch_rounds((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, sh, st, a, cb, bounce);
-    else if (dirOnly) launch_rounds((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, sh, st, a, cb, bounce);
-    else launch_rounds((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, sh, st, a, cb, bounce);
+    if (mode == kShadowSlim) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowSlim, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else if (dirOnly) hipLaunchKernelGGL((wf_shadow<false, D, 4, true, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
+    else hipLaunchKernelGGL((wf_shadow<false, D, 4, false, kShadowOpaque, TL>), g, dim3(kBlock), sh, st, a, cb, bounce);
 }
 template <int D, int TL> void launch_extend_two_level(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity)
 {
@@ -1650,7 +1652,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // wf_extend gets a grid of its own: a whole number of rounds of the six blocks a CU holds of it. Measured (scripts/env_sweep.sh
     // HRPT_WF_EXTEND_BLOCKS_PER_CU): tree in LDS 12 per CU (two rounds; 16 = 2.67 rounds: +8 % on config 2, the last round runs with four of six
     // slots filled), tree in global memory 6 (one persistent round: its waves are latency-bound and every further round re-pays the ramp:
-    // config 4 extend -6 %, glass config -20 %). The two-level kernels keep the general grid.
+    // config 4 extend -6 %, glass config -20 %). The two-level kernels keep the general grid (launch_rounds trims it to their five blocks per CU).
     const uint32_t extendBlocksPerCu = st.extendBlocksPerCu ? st.extendBlocksPerCu : (st.blocksPerCu ? st.blocksPerCu : (vE.twoLevel ? blocksPerCu : (vE.lds ? 12u : 6u)));
     const uint32_t maxBlocksPerCu = blocksPerCu > extendBlocksPerCu ? blocksPerCu : extendBlocksPerCu;
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
@@ -1714,7 +1716,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const bool timedEnds = st.profile && st.eventsUsed + 4 <= 4096;
         if (!fusedPrimary) {
             if (timedEnds) timing_mark(st, stream, 3, true);
-            launch_rounds(wf_raygen, dim3(grid), 0, stream, a, cb, jt);
+            hipLaunchKernelGGL(wf_raygen, dim3(grid), dim3(kBlock), 0, stream, a, cb, jt);
             if (timedEnds) timing_mark(st, stream, 3, false);
         }
         {   // raygen: sampleRadiance zeroed + one path record per pixel of the rectangle and index; resolve: sampleRadiance read, Accumulation
@@ -1743,8 +1745,8 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         auto shadow_stage = [&](hipStream_t sst, int bounce) {
             a.shadowParity = (uint32_t)bounce & 1u;
             if (shadowMode == kShadowResolve) {
-                if (traits.directionalLightsOnly) launch_rounds((wf_shadow_rays<true>), dim3(grid), 0, sst, a, cb);
-                else launch_rounds((wf_shadow_rays<false>), dim3(grid), 0, sst, a, cb);
+                if (traits.directionalLightsOnly) hipLaunchKernelGGL((wf_shadow_rays<true>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
+                else hipLaunchKernelGGL((wf_shadow_rays<false>), dim3(grid), dim3(kBlock), 0, sst, a, cb);
                 launch_extend(vA, dim3(grid), vA.ldsBytes, sst, a, 0u, true);
             }
             launch_shadow(vS, dim3(grid), vS.ldsBytes, sst, a, cb, bounce, traits.directionalLightsOnly, shadowMode);
@@ -1760,11 +1762,11 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
             const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
-            if (maxLights > kMaxLights) launch_rounds((wf_shade<0, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
-            else if (manyLights) launch_rounds((wf_shade<(int)kMaxLights, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
-            else if (simpleScene && a.primary) launch_rounds((wf_shade<1, true, true>), dim3(grid), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
-            else if (simpleScene) launch_rounds((wf_shade<1, true>), dim3(grid), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
-            else launch_rounds((wf_shade<1, false>), dim3(grid), sortLds, stream, a, cb, parity, bounce, last);
+            if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
+            else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
+            else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
+            else if (simpleScene) hipLaunchKernelGGL((wf_shade<1, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);
+            else hipLaunchKernelGGL((wf_shade<1, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             if (timed) { timing_mark(st, stream, 1, false); timing_mark(st, stream, 2, true); }
             if (overlap) {
                 if ((e = hipEventRecord(st.forkEvents[(size_t)bounce], stream)) != hipSuccess || (e = hipStreamWaitEvent(st.auxStream, st.forkEvents[(size_t)bounce], 0)) != hipSuccess) { error = "fork to the shadow stream"; return e; }
