@@ -1652,8 +1652,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     // wf_extend gets a grid of its own: a whole number of rounds of the six blocks a CU holds of it. Measured (scripts/env_sweep.sh
     // HRPT_WF_EXTEND_BLOCKS_PER_CU): tree in LDS 12 per CU (two rounds; 16 = 2.67 rounds: +8 % on config 2, the last round runs with four of six
     // slots filled), tree in global memory 6 (one persistent round: its waves are latency-bound and every further round re-pays the ramp:
-    // config 4 extend -6 %, glass config -20 %). The two-level kernels keep the general grid (launch_rounds trims it to their five blocks per CU).
-    const uint32_t extendBlocksPerCu = st.extendBlocksPerCu ? st.extendBlocksPerCu : (st.blocksPerCu ? st.blocksPerCu : (vE.twoLevel ? blocksPerCu : (vE.lds ? 12u : 6u)));
+    // config 4 extend -6 %, glass config -20 %; the two-level kernels hold five blocks per CU and launch_rounds trims the six to that: -6 / -10 %
+    // on instanced scenes of opaque / non-opaque materials).
+    const uint32_t extendBlocksPerCu = st.extendBlocksPerCu ? st.extendBlocksPerCu : (st.blocksPerCu ? st.blocksPerCu : (vE.lds ? 12u : 6u));
     const uint32_t maxBlocksPerCu = blocksPerCu > extendBlocksPerCu ? blocksPerCu : extendBlocksPerCu;
     if (vE.depth > kExtendLdsStack || vS.depth > kShadowLdsStack) {
         // stack overflow columns for trees whose worst-case stack need exceeds the LDS entries (see LdsStack); sized for the smaller LDS part

@@ -341,7 +341,7 @@ int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
  * in this form (an instance whose world matrix has no inverse, now or after a later hrpt_update_instances) is built flat whatever was
  * asked -- HrptBuildInfo::structure tells. AUTO: two-level when the scene has at least 2 M world triangles (16 M if any instance is non-opaque: measured cross-over) and at least 8
  * instances per distinct mesh on average (measured on MI355X, opaque spheres / cylinders of ~400 triangles, 1920x1080, 8 spp, 4 bounces:
- * 4 096 instances 19.1 ms flat vs 16.5 ms two-level, 16 384: 27.3 vs 17.6 ms, 65 536: 43.9 vs 18.8 ms and 17.6 GB vs 30 MB -- the small trees stay in cache).
+ * 4 096 instances 19.3 ms flat vs 16.2 ms two-level, 16 384: 27.7 vs 17.3 ms, 65 536: 44.4 vs 18.4 ms and 17.6 GB vs 30 MB -- the small trees stay in cache).
  * Takes effect at the next hrpt_upload_scene. */
 #define HRPT_ACCEL_AUTO      0
 #define HRPT_ACCEL_FLAT      1
