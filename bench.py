@@ -79,7 +79,25 @@ def _baseline_metric():
         return "Mrays/s at 1920\u00d71080, 8 spp, 4 bounces; 1/2/4/8 GPU scaling"
 
 
-def main():
+def _launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as FRESH child processes through
+    torch.distributed.run -- one per GPU, rendezvous on 127.0.0.1 at a free port -- relay their output (rank 0 prints the JSON line) and
+    return their exit status. The parent imports neither torch nor the HIP library before this point (tests/test_bench_contract.py), and it
+    starts children instead of replacing itself, so no process that has initialised a GPU is ever exec'ed over."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -107,14 +125,15 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="testing: run the N>1 code path (RCCL all-gather, comm stream) with a single rank")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json config: 2 = headline (Cornell-class), 4 = Sponza-class stand-in, 5 = glass stress stand-in")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has touched neither torch nor HIP) and exits with the ranks' status
+        raise SystemExit(_launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch

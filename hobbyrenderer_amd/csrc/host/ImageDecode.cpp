@@ -592,8 +592,11 @@ bool DecodeDDS(const uint8_t* d, size_t n, Image& out, std::string& err)
 
 
 // ------------------------------------------------------------------ JPEG (baseline / extended sequential / progressive Huffman, 8 bit)
-// Integer pipeline as in stb_image (public domain, not in the reference tree; the reference decodes through it): 12-bit fixed-point
-// inverse DCT of the jidctint family, triangle-filter chroma upsampling for 2x1 / 1x2 / 2x2, 20-bit fixed-point YCbCr -> RGB.
+// Integer pipeline restated from the decoder the reference vendors and decodes through, /root/reference/external/stb_image.h (public
+// domain; src/TextureLoader.cpp:225-257 calls stbi_load_from_memory(..., 4)): byte-identical texels need ITS arithmetic, so the 12-bit
+// fixed-point inverse DCT below follows stb_image.h:2430-2465 (STBI__IDCT_1D, the jidctint family) term by term, the chroma upsampling its
+// triangle filters for 2x1 / 1x2 / 2x2 (:3413-3540) and the colour conversion its 20-bit fixed-point YCbCr -> RGB (:3542-3570).
+// Pinned byte for byte against that header compiled as test infrastructure: tests/test_decoders_vs_stb.py (oracle/_ref/libstb_ref.so).
 // Progressive files keep the coefficients of every block over their scans (spectral selection + successive approximation, T.81 annex G)
 // and are transformed at the end. Arithmetic-coded files, 12-bit samples and CMYK are reported as unsupported.
 namespace {
@@ -773,6 +776,11 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
             }
             for (JComp& c : comps) if (hmax % c.h || vmax % c.v) { err = "unsupported JPEG sampling ratio"; return false; }
             int mcuX = (width + 8 * hmax - 1) / (8 * hmax), mcuY = (height + 8 * vmax - 1) / (8 * vmax);
+            {   // the planes are sized from this header alone: refuse a frame whose entropy-coded data cannot exist in the bytes that are left
+                // (every 8 x 8 block costs at least one DC code bit in its first scan), before allocating anything for it
+                size_t blocks = 0; for (const JComp& c : comps) blocks += (size_t)mcuX * c.h * (size_t)mcuY * c.v;
+                if (blocks / 8 > n - pos) { err = "JPEG frame of " + std::to_string(width) + " x " + std::to_string(height) + " announced by a file of " + std::to_string(n) + " bytes"; return false; }
+            }
             for (JComp& c : comps) {
                 c.x = (width * c.h + hmax - 1) / hmax; c.y = (height * c.v + vmax - 1) / vmax; c.w2 = mcuX * c.h * 8; c.h2 = mcuY * c.v * 8;
                 c.data.assign((size_t)c.w2 * c.h2 + 15, 0);
@@ -884,6 +892,11 @@ bool DecodeJPEG(const uint8_t* data, size_t n, Image& out, std::string& err)
                 for (int j = 0; j < h && ok; ++j) for (int i = 0; i < w && ok; ++i) { ok = one_block(c, i, j) && after_mcu(); }
             } else {
                 int mcuX = (width + 8 * hmax - 1) / (8 * hmax), mcuY = (height + 8 * vmax - 1) / (8 * vmax);
+            {   // the planes are sized from this header alone: refuse a frame whose entropy-coded data cannot exist in the bytes that are left
+                // (every 8 x 8 block costs at least one DC code bit in its first scan), before allocating anything for it
+                size_t blocks = 0; for (const JComp& c : comps) blocks += (size_t)mcuX * c.h * (size_t)mcuY * c.v;
+                if (blocks / 8 > n - pos) { err = "JPEG frame of " + std::to_string(width) + " x " + std::to_string(height) + " announced by a file of " + std::to_string(n) + " bytes"; return false; }
+            }
                 for (int j = 0; j < mcuY && ok; ++j) for (int i = 0; i < mcuX && ok; ++i) {
                     for (JComp* c : scan) for (int y = 0; y < c->v && ok; ++y) for (int x = 0; x < c->h && ok; ++x) ok = one_block(*c, i * c->h + x, j * c->v + y);
                     ok = ok && after_mcu();

@@ -48,3 +48,53 @@ def test_bench_command_line():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--serial-kernels", "--frames-in-flight"):
         assert flag in out.stdout
+
+
+def test_gpus_n_without_launcher_starts_fresh_ranks():
+    """`python bench.py --gpus N` as the driver types it (no torch.distributed.run, WORLD_SIZE unset): the parent turns into the launcher
+    BEFORE it imports torch or loads the HIP library (a process that touched the GPU must not fork ranks from itself), hands the ranks the
+    unchanged command line and a 127.0.0.1 rendezvous, and exits with their status."""
+    probe = r"""
+import json, os, subprocess, sys
+sys.path.insert(0, %r)
+os.environ.pop("WORLD_SIZE", None)
+import bench
+seen = {}
+def fake_call(cmd, env=None):
+    seen["cmd"] = cmd; seen["env_ipc"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    return 7
+subprocess.call = fake_call
+try:
+    bench.main(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    code = None
+except SystemExit as e:
+    code = e.code
+with open("/proc/self/maps") as f:
+    maps = f.read()
+print(json.dumps({"code": code, "cmd": seen.get("cmd"), "ipc": seen.get("env_ipc"),
+                  "torch": any(m == "torch" or m.startswith("torch.") for m in sys.modules),
+                  "hip": ("libhobbyrt_pt" in maps) or ("libamdhip64" in maps)}))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["code"] == 7                               # the ranks' exit status is the parent's
+    assert d["torch"] is False and d["hip"] is False    # nothing GPU-related was imported on the way
+    cmd = d["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert d["ipc"] == "0"
+
+
+def test_gpus_n_under_a_launcher_does_not_relaunch():
+    """With WORLD_SIZE set (torch.distributed.run started us) the rank path is taken: --help still parses, and _launch_ranks is not reached."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench, subprocess\n"
+                          "subprocess.call = lambda *a, **k: (_ for _ in ()).throw(AssertionError('relaunched'))\n"
+                          "bench._launch_ranks = lambda *a: (_ for _ in ()).throw(AssertionError('relaunched'))\n"
+                          "import argparse\n"
+                          "try:\n    bench.main(['--gpus', '2', '--help'])\nexcept SystemExit as e:\n    print('exit', e.code)\n" % ROOT],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0 and "exit 0" in out.stdout, out.stderr
