@@ -92,6 +92,20 @@ struct GpuNode {            // 64 B: both child boxes live in the parent -> one 
 struct GpuNode4 {           // 128 B: four child boxes in SoA + four child refs (bvh_build.h HostNode4); empty slot = far-away box
     float4 minx, maxx, miny, maxy, minz, maxz; int4 child; uint4 pad;     // rows at byte 0, 16, ..., 80; child refs at 96
 };
+// 64 B: the same four child boxes as a GpuNode4, quantised to 8 bits per plane relative to the node's own extent (origin = min corner of the
+// union of the child boxes, one fp32 step per axis), rounded OUTWARD (and checked against the decode arithmetic), so a decoded box contains the fp32 box it came
+// from (hrpt_selftest_bvh checks every node). What it buys: a lane's node fetch is 4 sixteen-byte requests instead of 7, and the L1 (TCP)
+// of a CU looks up about ONE lane-request per cycle whatever the request's width -- the traversal kernels on trees in global memory are
+// bound by exactly that rate (scripts/microbench/gather_nodes.hip; three more requests per step cost config 4's wf_extend +45 %).
+// Culling only: the hit definition never depends on the boxes. Rows: {ox, oy, oz, sx} {lo_x, hi_x, lo_y, hi_y}
+// {lo_z, hi_z, sy, sz} {child[4]}; byte c of a plane word belongs to child c; an unused slot has lo = 255 > hi = 0 on every axis.
+struct GpuNodeQ {
+    float ox, oy, oz, sx;
+    uint32_t lox, hix, loy, hiy;
+    uint32_t loz, hiz; float sy, sz;
+    int32_t child[4];
+};
+static_assert(sizeof(GpuNodeQ) == 64, "four 16-byte rows");
 struct GpuTri {             // 48 B world-space triangle (instance transform applied at upload)
     float p0[3]; uint32_t inst;
     float p1[3]; uint32_t prim;
@@ -117,6 +131,7 @@ struct GpuTexture {         // decoded texels of all levels (HrptTextureDesc); l
 struct SceneView {
     const GpuNode* nodes; uint32_t nodeCount;
     const GpuNode4* nodes4; uint32_t node4Count;   // the same tree collapsed to 4-wide nodes (wavefront kernels); root = 0
+    const GpuNodeQ* nodesQ;                         // nodes4 in the 64-byte quantised form, same indices (flat structure only; null otherwise)
     const GpuTri* tris; uint32_t triCount;
     int32_t rootLeaf;       // when the whole scene fits one leaf: encoded leaf, else 0
     const GpuTriAttr* attrs;            // parallel to tris
@@ -201,7 +216,7 @@ struct GlobalBvh {
 };
 
 struct GlobalBvh4 {
-    static constexpr int kWidth = 4; static constexpr bool kTwoLevel = false;
+    static constexpr int kWidth = 4; static constexpr bool kTwoLevel = false; static constexpr bool kLds = false;
     const GpuNode4* nodes; const GpuTri* tris;
     // Nodes and triangles are addressed as (array base, 32-bit byte offset): the base stays in scalar registers and a lane holds one VGPR per
     // address instead of a pair (global_load saddr + voffset form; 64-bit address arithmetic is two VALU operations per add on gfx950).
@@ -215,6 +230,20 @@ struct GlobalBvh4 {
     HRT_DEV uint32_t rowoff(int i, uint32_t byteOffset) const { return (uint32_t)i * 128u + byteOffset; }
     HRT_DEV float4 load(uint32_t off) const { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (size_t)off); }
 };
+
+// The flat 4-wide tree through its quantised nodes (GpuNodeQ): what the wavefront kernels traverse when the tree is not LDS-resident.
+struct GlobalBvhQ {
+    static constexpr int kWidth = 4; static constexpr bool kTwoLevel = false; static constexpr bool kLds = false; static constexpr bool kQuantised = true;
+    const GpuNodeQ* nodes; const GpuTri* tris;
+    HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const
+    {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (size_t)(i * 48u));
+        a = p[0]; b = p[1]; c = p[2];
+    }
+    HRT_DEV float4 row(int i, uint32_t r) const { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (size_t)((uint32_t)i * 64u + r * 16u)); }
+};
+template <class BVH, class = void> struct IsQuantised { static constexpr bool value = false; };
+template <class BVH> struct IsQuantised<BVH, decltype((void)BVH::kQuantised)> { static constexpr bool value = true; };
 
 // Conservative slab test of one child box against [t0, t1]. Culling only: it never changes which hit is
 // reported (the hit definition is BVH-independent), so it may use native min/max, the hardware reciprocal and
@@ -272,6 +301,33 @@ HRT_DEV int32_t inner_step(const BVH& bvh, int32_t cur, f3 noi, f3 noiF, f3 inv,
         if (hl && hr) { bool leftFirst = tl <= tr; stack.push(sp++, leftFirst ? ri : li); return leftFirst ? li : ri; }
         if (hl) return li;
         if (hr) return ri;
+        return (sp == 0) ? kTraversalDone : stack.pop(--sp);
+    } else if constexpr (IsQuantised<BVH>::value) {
+        // 64-byte quantised node: four requests. Plane distance of byte q of an axis: (o + q * s - ray.o) * inv = q * (s * inv) + (o * inv + noi);
+        // the near / far plane WORDS of an axis are picked by the sign of the direction, the byte of child c by v_cvt_f32_ubyte<c>.
+        const float4 r0 = bvh.row(cur, 0u), r1 = bvh.row(cur, 1u), r2 = bvh.row(cur, 2u), chf = bvh.row(cur, 3u);
+        const float ax = r0.w * inv.x, ay = r2.z * inv.y, az = r2.w * inv.z;
+        const float bx = __builtin_fmaf(r0.x, inv.x, noi.x), by = __builtin_fmaf(r0.y, inv.y, noi.y), bz = __builtin_fmaf(r0.z, inv.z, noi.z);
+        const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
+        const uint32_t wnx = __float_as_uint(negx ? r1.y : r1.x), wfx = __float_as_uint(negx ? r1.x : r1.y);
+        const uint32_t wny = __float_as_uint(negy ? r1.w : r1.z), wfy = __float_as_uint(negy ? r1.z : r1.w);
+        const uint32_t wnz = __float_as_uint(negz ? r2.y : r2.x), wfz = __float_as_uint(negz ? r2.x : r2.y);
+        auto boxq = [&](uint32_t sh) {
+            const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)((wnx >> sh) & 255u), ax, bx), __builtin_fmaf((float)((wny >> sh) & 255u), ay, by)),
+                                                             __builtin_fmaf((float)((wnz >> sh) & 255u), az, bz)), tmin);
+            const float far3 = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)((wfx >> sh) & 255u), ax, bx), __builtin_fmaf((float)((wfy >> sh) & 255u), ay, by)),
+                                               __builtin_fmaf((float)((wfz >> sh) & 255u), az, bz));
+            const float hi = __builtin_fminf(far3, tlim) * (1.0f + 4e-6f);       // as below: the scale after the clamp to tlim
+            return lo <= hi ? lo : __builtin_inff();
+        };
+        float t0 = boxq(0u), t1 = boxq(8u), t2 = boxq(16u), t3 = boxq(24u);
+        int32_t r0i = __float_as_int(chf.x), r1i = __float_as_int(chf.y), r2i = __float_as_int(chf.z), r3i = __float_as_int(chf.w);
+        cswap(t0, r0i, t1, r1i); cswap(t2, r2i, t3, r3i); cswap(t0, r0i, t2, r2i); cswap(t1, r1i, t3, r3i); cswap(t1, r1i, t2, r2i);
+        const float inf = __builtin_inff();
+        if (t3 < inf) stack.push(sp++, r3i);
+        if (t2 < inf) stack.push(sp++, r2i);
+        if (t1 < inf) stack.push(sp++, r1i);
+        if (t0 < inf) return r0i;
         return (sp == 0) ? kTraversalDone : stack.pop(--sp);
     } else {
         // The sign of the ray direction says which plane of every slab is the near one, so the near / far rows of the node are picked by

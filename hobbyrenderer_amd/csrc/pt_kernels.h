@@ -9,6 +9,7 @@
 namespace hrt {
 
 struct SceneView;   // pt_device.h
+struct GpuNode4; struct GpuNodeQ;
 
 constexpr int kCounterShards = 32;   // DeviceCounters[kCounterShards] per context; a block adds to shard blockIdx % kCounterShards
 struct DeviceCounters {         // 64 B; summed over the shards by hrpt_get_stats. The wavefront kernels address the fields by word index.
@@ -42,6 +43,9 @@ hipError_t launch_post_chain(const float4* hdr, float4* display, uint32_t pixelC
 // Batch ray queries (hrpt_trace_rays): closest hit with the candidate rules of TraceRayStandard, or NEE-style visibility.
 hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRayHit* hits, uint64_t count, bool shadow, hipStream_t stream);
 
+// The flat 4-wide tree in its 64-byte quantised form (pt_device.h GpuNodeQ): out[i] from nodes4[i]. leafArea (two zeroed doubles, or null)
+// receives the summed surface area of the leaf boxes before / after the rounding: what the looser boxes will cost in triangle tests.
+hipError_t launch_quantise_nodes(const GpuNode4* nodes4, uint32_t count, GpuNodeQ* out, double* leafArea, hipStream_t stream);
 // Self-test: counts child boxes of the 2-wide and 4-wide trees that do not contain their subtree's boxes / triangle vertices (0 = sound).
 hipError_t launch_bvh_check(const SceneView& scene, unsigned long long* violations, hipStream_t stream);
 // Self-test: out[i] = device decode of the binary16 pattern i, i in [0, 65536).

@@ -207,7 +207,81 @@ __global__ void pt_bvh_check_kernel(SceneView s, unsigned long long* violations)
             } else if (!leaf_in(s, ch[c], mn, mx)) ++bad;
         }
     }
+    if (s.nodesQ && i < s.node4Count) {                 // ... and its quantised form: every decoded box contains the fp32 box it was made from
+        const GpuNode4& n = s.nodes4[i]; const GpuNodeQ& q = s.nodesQ[i];
+        const float* r[6] = { &n.minx.x, &n.miny.x, &n.minz.x, &n.maxx.x, &n.maxy.x, &n.maxz.x };
+        const float o[3] = { q.ox, q.oy, q.oz }, st[3] = { q.sx, q.sy, q.sz };
+        const uint32_t lo[3] = { q.lox, q.loy, q.loz }, hi[3] = { q.hix, q.hiy, q.hiz };
+        const int32_t* ch = &n.child.x;
+        for (int c = 0; c < 4; ++c) {
+            if (q.child[c] != ch[c]) ++bad;
+            for (int a = 0; a < 3; ++a) {
+                const float dlo = o[a] + (float)((lo[a] >> (8 * c)) & 255u) * st[a], dhi = o[a] + (float)((hi[a] >> (8 * c)) & 255u) * st[a];
+                if (ch[c] == 0x7fffffff) { if (!(dlo > dhi)) ++bad; }                 // unused slot: an empty interval on every axis
+                else if (!(dlo <= r[a][c] && dhi >= r[3 + a][c]) || !(st[a] > 0.0f)) ++bad;
+            }
+        }
+    }
     if (bad) atomicAdd(violations, (unsigned long long)bad);
+}
+// GpuNode4 -> GpuNodeQ (see pt_device.h), one thread per node; run after every build / rebuild of the flat structure, whichever builder made it.
+__global__ void pt_quantise_nodes_kernel(const GpuNode4* __restrict__ in, uint32_t count, GpuNodeQ* __restrict__ out, double* __restrict__ leafArea)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const GpuNode4 n = in[i];
+    const float* r[6] = { &n.minx.x, &n.miny.x, &n.minz.x, &n.maxx.x, &n.maxy.x, &n.maxz.x };
+    const int32_t* ch = &n.child.x;
+    float o[3], st[3]; uint32_t lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        float mn = 3.0e38f, mx = -3.0e38f;
+        for (int c = 0; c < 4; ++c) if (ch[c] != 0x7fffffff) { mn = fminf(mn, r[a][c]); mx = fmaxf(mx, r[3 + a][c]); }
+        // 254 steps span the extent (the top plane may still need one step outward after rounding)
+        float step = (mx - mn) * (1.0f / 254.0f) * 1.000001f;
+        step = fmaxf(step, fmaxf(fabsf(mn), fabsf(mx)) * 2.4e-7f);       // never below two ulps of the coordinates: the slack must outweigh the rounding of o + q * s
+        step = fmaxf(step, 1.0e-30f);
+        o[a] = mn; st[a] = step; lo[a] = 0u; hi[a] = 0u;
+        for (int c = 0; c < 4; ++c) {
+            uint32_t ql = 255u, qh = 0u;
+            if (ch[c] != 0x7fffffff) {
+                float fl = floorf((r[a][c] - mn) / step), fh = ceilf((r[3 + a][c] - mn) / step);
+                fl = fminf(fmaxf(fl, 0.0f), 255.0f); fh = fminf(fmaxf(fh, 0.0f), 255.0f);
+                ql = (uint32_t)fl; qh = (uint32_t)fh;
+                // exactly the decode the self-test uses: step outward until the decoded plane is on the right side (at most a step or two)
+                while (ql > 0u && !(mn + (float)ql * step <= r[a][c])) --ql;
+                while (qh < 255u && !(mn + (float)qh * step >= r[3 + a][c])) ++qh;
+            }
+            lo[a] |= ql << (8 * c); hi[a] |= qh << (8 * c);
+        }
+    }
+    // what the rounding costs: surface area of the LEAF boxes before and after (the chance that a ray enters a box grows with its area, and
+    // every entered leaf is three requests and a watertight test per triangle): leafArea[0] += fp32 area, leafArea[1] += decoded area
+    if (leafArea) {
+        double a0 = 0.0, a1 = 0.0, r0 = 0.0, r1 = 0.0;
+        for (int c = 0; c < 4; ++c) {
+            if (ch[c] == 0x7fffffff || ch[c] >= 0) continue;
+            float e0[3], e1[3];
+            for (int a = 0; a < 3; ++a) {
+                e0[a] = r[3 + a][c] - r[a][c];
+                e1[a] = (o[a] + (float)((hi[a] >> (8 * c)) & 255u) * st[a]) - (o[a] + (float)((lo[a] >> (8 * c)) & 255u) * st[a]);
+            }
+            const double s0 = (double)e0[0] * e0[1] + (double)e0[1] * e0[2] + (double)e0[2] * e0[0], s1 = (double)e1[0] * e1[1] + (double)e1[1] * e1[2] + (double)e1[2] * e1[0];
+            a0 += s0; a1 += s1;
+            if (s0 > 0.0) { r0 += s1 / s0; r1 += 1.0; }
+        }
+        if (a0 > 0.0 || a1 > 0.0) { atomicAdd(&leafArea[0], a0); atomicAdd(&leafArea[1], a1); atomicAdd(&leafArea[2], r0); atomicAdd(&leafArea[3], r1); }
+    }
+    GpuNodeQ q;
+    q.ox = o[0]; q.oy = o[1]; q.oz = o[2]; q.sx = st[0]; q.sy = st[1]; q.sz = st[2];
+    q.lox = lo[0]; q.hix = hi[0]; q.loy = lo[1]; q.hiy = hi[1]; q.loz = lo[2]; q.hiz = hi[2];
+    for (int c = 0; c < 4; ++c) q.child[c] = ch[c];
+    out[i] = q;
+}
+hipError_t launch_quantise_nodes(const GpuNode4* nodes4, uint32_t count, GpuNodeQ* out, double* leafArea, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_quantise_nodes_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, nodes4, count, out, leafArea);
+    return hipGetLastError();
 }
 hipError_t launch_bvh_check(const SceneView& scene, unsigned long long* violations, hipStream_t stream)
 {

@@ -23,6 +23,7 @@ struct SceneTraits {
     bool hasNonOpaque = false;         // some instance is ForceNonOpaque (material alpha mode MASK or BLEND)
     uint32_t bvhMaxDepth = 0;
     uint32_t bvh4MaxDepth = 0;
+    bool quantisedNodes = false;       // trees in global memory are walked through SceneView::nodesQ (64-byte nodes): chosen per scene at build time (pt_capi.cpp)
     uint32_t twoLevelStackNeed = 0;    // != 0: the scene holds the two-level structure (SceneView::instances); worst-case traversal stack entries
 };
 
@@ -51,6 +52,7 @@ struct WavefrontState {
     bool profile = false;              // record HIP events around every extend / shade / shadow launch (HRPT_FRAME_PROFILE)
     uint32_t refillMin = 0;            // wf_extend lane-refill threshold (1..64); 0 = default
     uint32_t segmentShift = 0;         // log2 of the segment size (6..10); 0 = automatic
+    uint32_t segmentSize = 0;          // a segment size that is not a power of two (64..1024); 0 = from segmentShift
     bool forceGlobalBvh = false;
     bool drainSegments = false;        // wf_extend finishes every ray of a segment before it opens the next one (A/B knob)
     bool serialShadow = false;         // true: wf_shadow runs in stream order instead of concurrently with the next wf_extend

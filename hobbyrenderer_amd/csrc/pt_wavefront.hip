@@ -38,7 +38,7 @@ namespace hrt {
 
 namespace {
 
-constexpr uint32_t kMaxSegment = 1024;       // samples per wave-owned segment: 2^segShift, 64..1024, chosen per batch
+constexpr uint32_t kMaxSegment = 1024;       // largest wave-owned segment (samples); the size is chosen per batch, 64..1024
 constexpr uint32_t kBlock = 256;             // 4 waves
 constexpr uint32_t kMaxLights = 8;
 constexpr uint32_t kMaxSppPerBatch = 64;
@@ -61,7 +61,7 @@ struct WfBuffers {
 struct WfArgs {
     SceneView scene;
     WfBuffers b;
-    uint32_t segShift;         // log2(segment size)
+    uint32_t segSize;          // samples per segment (any size from 64 to kMaxSegment: chosen per batch so that the segments divide evenly among the waves of the grids)
     uint32_t numSegments;      // segments in this batch
     uint32_t numSamples;       // tilesX*tilesY*64*spp (padded to 8x8 pixel tiles)
     uint32_t pixelsPadded;     // tilesX*tilesY*64
@@ -128,7 +128,7 @@ HRT_DEV bool primary_ray(const WfArgs& a, const PrimaryArgs& pr, uint32_t smp, f
 HRT_DEV uint32_t path_count(const WfArgs& a, uint32_t in, uint32_t seg)
 {
     (void)in;
-    const uint32_t base = seg << a.segShift, left = a.numSamples - base, size = 1u << a.segShift; return left < size ? left : size;
+    const uint32_t base = seg * a.segSize, left = a.numSamples - base, size = a.segSize; return left < size ? left : size;
 }
 
 // per-lane traversal stack in LDS: element (sp, lane-in-block) at base[sp * kBlock]
@@ -181,7 +181,7 @@ struct GlobalCandidates {
 // BVH copy in LDS; W = node width (2: GpuNode, 4: GpuNode4)
 template <int W>
 struct LdsBvh {
-    static constexpr int kWidth = W; static constexpr bool kTwoLevel = false;
+    static constexpr int kWidth = W == 5 ? 4 : W; static constexpr bool kTwoLevel = false; static constexpr bool kLds = true;
     const float4* nodes; const float4* tris;
     HRT_DEV void node(int i, float4& a, float4& b, float4& c, float4& d) const { const float4* p = nodes + 4 * i; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
@@ -195,6 +195,8 @@ template <> struct GlobalBvhOf<2> { using type = GlobalBvh; static HRT_DEV Globa
 constexpr int kTwoLevelTree = 44;     // GlobalBvhOf key of the two-level structure (4-wide nodes)
 template <> struct GlobalBvhOf<kTwoLevelTree> { using type = GlobalBvhTl; static HRT_DEV GlobalBvhTl make(const SceneView& s) { GlobalBvhTl g; g.nodes = s.nodes4; g.tris = s.tris; g.instances = s.instances; return g; } };
 template <> struct GlobalBvhOf<4> { using type = GlobalBvh4; static HRT_DEV GlobalBvh4 make(const SceneView& s) { GlobalBvh4 g; g.nodes = s.nodes4; g.tris = s.tris; return g; } };
+constexpr int kQuantisedTree = 5;     // template width code of the 4-wide tree through its 64-byte quantised nodes (global memory only; pt_device.h GpuNodeQ)
+template <> struct GlobalBvhOf<kQuantisedTree> { using type = GlobalBvhQ; static HRT_DEV GlobalBvhQ make(const SceneView& s) { GlobalBvhQ g; g.nodes = s.nodesQ; g.tris = s.tris; return g; } };
 
 // Carves dynamic LDS: [stack: min(DEPTH, 32)*kBlock ints][bvh copy]; copies the BVH when LDS_BVH.
 template <bool LDS_BVH, int DEPTH, int W, int LDSMAX>
@@ -273,10 +275,11 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     unsigned int nPaths = 0;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        uint32_t segBase = seg << a.segShift, outCount = 0;
-        for (uint32_t base = 0; base < (1u << a.segShift); base += 64) {
+        uint32_t segBase = seg * a.segSize, outCount = 0;
+        for (uint32_t base = 0; base < a.segSize; base += 64) {
             uint32_t smp = segBase + base + lane;
-            bool active = smp < a.numSamples;
+            const bool mine = base + lane < a.segSize && smp < a.numSamples;      // (a segment need not be a multiple of 64 samples)
+            bool active = mine;
             uint32_t k = 0, px = 0, py = 0;
             if (active) {
                 k = smp / a.pixelsPadded;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
                 py = a.rect.y0 + trow * 8u + (within >> 3);
                 active = px < a.rect.x1 && py < a.rect.y1;
             }
-            if (smp < a.numSamples) a.b.radiance[smp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (mine) a.b.radiance[smp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             unsigned long long m = __ballot(active);
             if (active) {
                 PathState ps;
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
 {
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
     static_assert(!PRIMARY || !ANYHIT, "primary rays are closest-hit rays");
+    static_assert(W != kQuantisedTree || (!LDS_BVH && !TL), "quantised nodes: flat tree in global memory");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = ANYHIT ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
                 cnt = uniform(PRIMARY ? path_count(a, 0u, seg) : segCount[seg]);
-                if (cnt) { segBase = (seg << a.segShift) * slotsPerSample; haveSeg = true; break; }
+                if (cnt) { segBase = (seg * a.segSize) * slotsPerSample; haveSeg = true; break; }
             }
         };
         open_segment();
@@ -551,12 +555,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
 struct WfTraceArgs {
     SceneView scene; const HrptRay* rays; HrptRayHit* hits; uint64_t count;
     int32_t* spill; uint32_t refillMin, nodeLoopMin;
+    bool quantised;         // host-side only: the launch picks the instantiation that walks SceneView::nodesQ
 };
 constexpr uint32_t kTraceChunkShift = 8;
 template <bool LDS_BVH, int DEPTH, int W, bool SHADOW, bool TL = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SHADOW ? 1 : (TL ? kWavesExtendTwoLevel : (LDS_BVH ? kWavesExtendLds : kWavesExtendGlobal))))) void wf_trace_rays(WfTraceArgs a)
 {
     static_assert(!TL || (!LDS_BVH && W == 4), "two-level structure: global 4-wide trees (every instance opaque: a shadow ray ends at its first hit)");
+    static_assert(W != kQuantisedTree || (!LDS_BVH && !TL), "quantised nodes: flat tree in global memory");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     LdsStack<DEPTH, kExtendLdsStack> stack; LdsBvh<W> lbvh;
     constexpr size_t candBytes = SHADOW ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWavesSh
     // shade_surface_a / miss_sky with a fraction of the lanes. Per path nothing changes: every path carries its RNG state and sample index,
     // and survivors / NEE entries still compact into their own segment, only in another order.
     constexpr bool SORT = !SIMPLE;
-    const uint32_t segSize = 1u << a.segShift;
+    const uint32_t segSize = a.segSize;
     // two permutation tables per wave (the open segment A and its successor B, which fills the lanes A's last iteration leaves empty) + keys
     uint16_t* const permBase = reinterpret_cast<uint16_t*>(shadeSmem) + (size_t)uniform(threadIdx.x >> 6) * segSize * 2;
     uint8_t* const keys = reinterpret_cast<uint8_t*>(shadeSmem) + (size_t)wavesPerBlock * segSize * 4 + (size_t)uniform(threadIdx.x >> 6) * segSize;
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWavesSh
             haveSeg = false; cnt = 0; next = 0; outCount = 0; shCount = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
                 cnt = uniform(PRIMARY ? path_count(a, in, seg) : a.b.pathCnt[in][seg]);
-                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+                if (cnt) { segBase = seg * a.segSize; haveSeg = true; break; }
                 if (lane == 0) { a.b.pathCnt[out][seg] = 0; a.b.shadowCnt[seg] = 0; }
             }
             if (SORT && a.sortShade && haveSeg) permuted = sort_segment(segBase, cnt, permBase + permSel * segSize);
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWavesSh
                     if (lane == 0) { a.b.pathCnt[out][probe] = 0; a.b.shadowCnt[probe] = 0; }
                 }
                 if (probe < a.numSegments) {
-                    segB = probe; baseB = probe << a.segShift; takeB = cntB < 64u - takeA ? cntB : 64u - takeA;
+                    segB = probe; baseB = probe * a.segSize; takeB = cntB < 64u - takeA ? cntB : 64u - takeA;
                     if (SORT && a.sortShade) permutedB = sort_segment(baseB, cntB, permBase + (permSel ^ 1u) * segSize);
                 } else segB = probe;          // no further segment: remembered so that the cursor below ends the loop
             }
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_rays(WfArgs a, HrptPathTrace
     const uint32_t wavesPerBlock = kBlock / 64, lane = lane_id();
     const uint32_t gw = uniform(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)), totalWaves = gridDim.x * wavesPerBlock;
     for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-        const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg << a.segShift, items = cnt * a.maxLights;
+        const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg * a.segSize, items = cnt * a.maxLights;
         uint32_t outCount = 0;
         for (uint32_t i0 = 0; i0 < items; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -1055,6 +1061,7 @@ template <bool LDS_BVH, int DEPTH, int W, bool DIRONLY, int MODE, int TL = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 2 && TL == 0 ? 4 : ((MODE == 1 || TL != 0) ? 3 : 1)))) void wf_shadow(WfArgs a, HrptPathTracerConstants cb, int bounce)
 {
     static_assert(!TL || (!LDS_BVH && W == 4 && (MODE == kShadowOpaque || MODE == kShadowSlim)), "two-level structure: opaque any-hit query over the global tree");
+    static_assert(W != kQuantisedTree || (!LDS_BVH && !TL), "quantised nodes: flat tree in global memory");
     constexpr bool NONOPAQUE = MODE == kShadowBuffered || MODE == kShadowResolve;
     constexpr bool SLIM = MODE == kShadowSlim;
     constexpr int kLdsMax = MODE == kShadowResolve ? kExtendLdsStack : kShadowLdsStack;
@@ -1187,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
             haveSeg = false; cnt = 0; next = 0;
             for (; seg < a.numSegments; seg += totalWaves) {
                 cnt = uniform(a.b.shadowCnt[seg]);
-                if (cnt) { segBase = seg << a.segShift; haveSeg = true; break; }
+                if (cnt) { segBase = seg * a.segSize; haveSeg = true; break; }
             }
         };
         open_segment();
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
         }
     } else {
         for (uint32_t seg = gw; seg < a.numSegments; seg += totalWaves) {
-            const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg << a.segShift;
+            const uint32_t cnt = uniform(a.b.shadowCnt[seg]), segBase = seg * a.segSize;
             for (uint32_t base = 0; base < cnt; base += 64) {
                 uint32_t i = base + lane;
                 if (i < cnt) process(segBase + i);
@@ -1272,11 +1279,11 @@ template <class K, class... Args> static void launch_rounds(K kernel, dim3 g, si
     if (perRound && g.x > perRound) g.x = (g.x / perRound) * perRound;
     hipLaunchKernelGGL(kernel, g, dim3(kBlock), ldsBytes, st, args...);
 }
-struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; bool twoLevelCandidates = false; };
+struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel = false; bool twoLevelCandidates = false; bool quantised = false; };
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
-    if constexpr (W == 4) if (a.primary && !anyHit) { launch_rounds((wf_extend<L, D, W, false, false, true>), g, sh, st, a, parity); return; }
+    if constexpr (W >= 4) if (a.primary && !anyHit) { launch_rounds((wf_extend<L, D, W, false, false, true>), g, sh, st, a, parity); return; }
     if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
     else launch_rounds((wf_extend<L, D, W, false>), g, sh, st, a, parity);
 }
@@ -1300,6 +1307,10 @@ template <bool L> void launch_extend_l(Variant v, dim3 g, size_t sh, hipStream_t
     if (v.width == 2) {
         if (v.depth <= 8) launch_extend_t<L, 8, 2>(g, sh, st, a, parity, anyHit); else if (v.depth <= 16) launch_extend_t<L, 16, 2>(g, sh, st, a, parity, anyHit); else if (v.depth <= 32) launch_extend_t<L, 32, 2>(g, sh, st, a, parity, anyHit); else launch_extend_t<L, 64, 2>(g, sh, st, a, parity, anyHit);
     } else {
+        if constexpr (!L) if (v.quantised) {
+            if (v.depth <= 16) launch_extend_t<L, 16, kQuantisedTree>(g, sh, st, a, parity, anyHit); else if (v.depth <= 32) launch_extend_t<L, 32, kQuantisedTree>(g, sh, st, a, parity, anyHit); else launch_extend_t<L, 64, kQuantisedTree>(g, sh, st, a, parity, anyHit);
+            return;
+        }
         if (v.depth <= 16) launch_extend_t<L, 16, 4>(g, sh, st, a, parity, anyHit); else if (v.depth <= 32) launch_extend_t<L, 32, 4>(g, sh, st, a, parity, anyHit); else launch_extend_t<L, 64, 4>(g, sh, st, a, parity, anyHit);
     }
 }
@@ -1308,6 +1319,10 @@ template <bool L> void launch_shadow_l(Variant v, dim3 g, size_t sh, hipStream_t
     if (v.width == 2) {
         if (v.depth <= 8) launch_shadow_t<L, 8, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 16) launch_shadow_t<L, 16, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 2>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     } else {
+        if constexpr (!L) if (v.quantised) {
+            if (v.depth <= 16) launch_shadow_t<L, 16, kQuantisedTree>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, kQuantisedTree>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, kQuantisedTree>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
+            return;
+        }
         if (v.depth <= 16) launch_shadow_t<L, 16, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else if (v.depth <= 32) launch_shadow_t<L, 32, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque); else launch_shadow_t<L, 64, 4>(g, sh, st, a, cb, bounce, dirOnly, nonOpaque);
     }
 }
@@ -1353,6 +1368,7 @@ void launch_shadow(Variant v, dim3 g, size_t sh, hipStream_t st, const WfArgs& a
 namespace {
 template <bool L, int D, bool SH> void launch_trace_rays_t(dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
 {
+    if constexpr (!L) if (a.quantised) { launch_rounds((wf_trace_rays<L, D, kQuantisedTree, SH>), g, lds + (SH ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0), st, a); return; }
     launch_rounds((wf_trace_rays<L, D, 4, SH>), g, lds + (SH ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0), st, a);
 }
 template <bool L, bool SH> void launch_trace_rays_d(int depth, dim3 g, size_t lds, hipStream_t st, const WfTraceArgs& a)
@@ -1387,6 +1403,7 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     a.scene = scene; a.rays = rays; a.hits = hits; a.count = count;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
     a.nodeLoopMin = st.nodeLoopMin != ~0u ? st.nodeLoopMin : (lds ? 16u : 24u);
+    a.quantised = !twoLevel && !lds && traits.quantisedNodes && scene.nodesQ != nullptr;
     if (depth > kExtendLdsStack) {
         // own overflow columns (a render may be in flight on the context's buffers only in stream order, but sizes differ)
         const uint32_t entries = need > (uint32_t)kExtendLdsStack ? need - kExtendLdsStack : 1u;
@@ -1613,6 +1630,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         const size_t stackBytes = (size_t)(v.depth > ldsStackMax ? ldsStackMax : v.depth) * kBlock * 4;
         v.lds = bvhBytes > 0 && stackBytes + extraBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
         v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0) + st.padLdsBytes;
+        v.quantised = v.width == 4 && !v.lds && traits.quantisedNodes && scene.nodesQ != nullptr;
         return v;
     };
     const int forced = st.bvhWidth == 2 ? 2 : (st.bvhWidth == 4 ? 4 : 0);
@@ -1685,8 +1703,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         uint32_t shift = st.segmentShift ? st.segmentShift : (largeBatch ? 9u : 8u);
         if (shift < 6) shift = 6;
         if (shift > 10) shift = 10;
-        a.segShift = shift;
-        a.numSegments = (a.numSamples + (1u << shift) - 1) >> shift;
+        a.segSize = 1u << shift;
+        if (st.segmentSize >= 64u && st.segmentSize <= kMaxSegment) a.segSize = st.segmentSize;       // HRPT_WF_SEGMENT_SIZE: any size (experiments)
+        a.numSegments = (a.numSamples + a.segSize - 1) / a.segSize;
         const uint32_t wavesNeeded = a.numSegments, blocksNeeded = (wavesNeeded + 3) / 4;
         uint32_t grid = cus * blocksPerCu; if (grid > blocksNeeded) grid = blocksNeeded; if (grid == 0) grid = 1;
         uint32_t gridExtend = cus * extendBlocksPerCu; if (gridExtend > blocksNeeded) gridExtend = blocksNeeded; if (gridExtend == 0) gridExtend = 1;
@@ -1762,7 +1781,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
             if (timed) { timing_mark(st, stream, 0, false); timing_mark(st, stream, 1, true); }
             if (pendingJoin) { if ((e = hipStreamWaitEvent(stream, st.joinEvents[(size_t)bounce - 1], 0)) != hipSuccess) { error = "hipStreamWaitEvent(join)"; return e; } pendingJoin = false; }
             const int last = bounce + 1 == maxBounces ? 1 : 0;
-            const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 << a.segShift);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
+            const size_t sortLds = (size_t)(kBlock / 64) * ((size_t)5 * a.segSize);      // per wave: two uint16 permutations (segments A, B) + uint8 class keys
             if (maxLights > kMaxLights) hipLaunchKernelGGL((wf_shade<0, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (manyLights) hipLaunchKernelGGL((wf_shade<(int)kMaxLights, false>), dim3(grid), dim3(kBlock), sortLds, stream, a, cb, parity, bounce, last);
             else if (simpleScene && a.primary) hipLaunchKernelGGL((wf_shade<1, true, true>), dim3(grid), dim3(kBlock), (kBlock / 64) * kShadeRing * 23 * 4, stream, a, cb, parity, bounce, last);

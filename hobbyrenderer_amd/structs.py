@@ -138,7 +138,7 @@ class BuildInfo(C.Structure):      # HrptBuildInfo, 64 B
     _fields_ = [("requestedBuilder", C.c_uint32), ("usedBuilder", C.c_uint32), ("buildMs", C.c_float), ("deviceBuildMs", C.c_float),
                 ("triangleCount", C.c_uint32), ("nodeCount", C.c_uint32), ("node4Count", C.c_uint32), ("maxDepth", C.c_uint32),
                 ("maxDepth4", C.c_uint32), ("mortonBits", C.c_uint32), ("sahCost", C.c_float), ("structure", C.c_uint32),
-                ("instanceNodeCount", C.c_uint32), ("distinctMeshes", C.c_uint32), ("pad", C.c_uint32 * 2)]
+                ("instanceNodeCount", C.c_uint32), ("distinctMeshes", C.c_uint32), ("leafAreaPermille", C.c_uint32), ("nodeFormat", C.c_uint32)]
 
 
 ABI_VERSION = 3                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)

@@ -324,7 +324,9 @@ typedef struct HrptBuildInfo {
     uint32_t structure;                         /* HRPT_ACCEL_FLAT or HRPT_ACCEL_TWO_LEVEL: what the last build produced */
     uint32_t instanceNodeCount;                 /* two-level: 4-wide nodes of the tree over the instances (node4Count counts those + the mesh trees) */
     uint32_t distinctMeshes;                    /* two-level: meshes with a tree of their own (triangleCount counts THEIR triangles, not instances x triangles) */
-    uint32_t pad[2];
+    uint32_t leafAreaPermille;                  /* flat structure: surface area of the leaf boxes in the 64-byte quantised nodes / in the fp32 nodes, x 1000 (0: no tree) */
+    uint32_t nodeFormat;                        /* what the wavefront kernels walk when the tree is in global memory: 1 = 128-byte fp32 nodes, 2 = 64-byte quantised nodes
+                                                   (four instead of seven 16-byte requests per lane and step; chosen when leafAreaPermille <= 1100; HRPT_BVH_NODE_FORMAT=1|2 forces) */
 } HrptBuildInfo;                                /* 64 B */
 int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
 

@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["HRPT_LIBRARY"] = os.path.join(ROOT, "hobbyrenderer_amd", "libhobbyrt_pt_phases.so")
+os.environ["HRPT_LIBRARY"] = os.environ.get("HRPT_PHASES_LIBRARY") or os.path.join(ROOT, "hobbyrenderer_amd", "libhobbyrt_pt_phases.so")
 sys.path.insert(0, ROOT)
 import numpy as np
 from hobbyrenderer_amd import native, scenes, structs as S

@@ -286,6 +286,54 @@ def test_forced_bvh_width(luts, width, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("fmt", [1, 2], ids=["fp32_nodes", "quantised_nodes"])
+def test_forced_node_format(luts, fmt, monkeypatch):
+    """Trees in global memory are walked through the 128-byte fp32 nodes or through their 64-byte quantised form (pt_device.h GpuNodeQ; chosen
+    per scene by the leaf-area ratio, HRPT_BVH_NODE_FORMAT forces, read at every build). The boxes only cull, so both formats are bit-exact
+    against the oracle: closest-hit and shadow kernels of both shadow schedules, stand-alone ray queries, and after a rebuild; the device
+    self-test confirms that every decoded box contains the fp32 box it was rounded from."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    monkeypatch.setenv("HRPT_BVH_NODE_FORMAT", str(fmt))
+    for path in ("1", "2"):
+        monkeypatch.setenv("HRPT_WF_SHADOW_PATH", path)
+        c = PathTracerContext(0)
+        try:
+            for builder in (S.BVH_BUILDER_HOST_SAH, S.BVH_BUILDER_GPU_PLOC):
+                c.set_bvh_builder(builder)
+                sc, view, pos, cfg = scenes.config_glass(luts, 96, 54, detail=0.5)
+                _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+                bi = c.build_info()
+                assert bi.nodeFormat == fmt and bi.leafAreaPermille >= 1000 and c.selftest_bvh() == 0
+                sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=0.5, tex_size=32)
+                _assert_parity(*_run_both(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_WAVEFRONT))
+                assert c.build_info().nodeFormat == fmt and c.selftest_bvh() == 0
+        finally:
+            c.close()
+
+
+def test_node_format_ray_queries_agree(luts, monkeypatch):
+    """hrpt_trace_rays over the same scene with both node formats: identical records ray by ray (closest hit and visibility)."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    sc = scenes.config_sponza_class(luts, 96, 54, detail=0.5, tex_size=32)[0]
+    rng = np.random.default_rng(11)
+    rays = np.zeros(20000, S.Ray)
+    rays["origin"] = (rng.random((len(rays), 3)).astype(np.float32) - np.float32(0.5)) * np.float32(20.0) + np.array([0, 4, 0], np.float32)
+    d = rng.normal(size=(len(rays), 3)); rays["direction"] = (d / np.sqrt((d ** 2).sum(1, keepdims=True))).astype(np.float32)
+    rays["tmax"] = 1e10; rays["rng"] = rng.integers(0, 2 ** 32, len(rays), dtype=np.uint64).astype(np.uint32)
+    out = {}
+    for fmt in (1, 2):
+        monkeypatch.setenv("HRPT_BVH_NODE_FORMAT", str(fmt))
+        c = PathTracerContext(0)
+        try:
+            c.upload_scene(sc)
+            assert c.build_info().nodeFormat == fmt
+            out[fmt] = (c.trace_rays(rays).tobytes(), c.trace_rays(rays, shadow=True).tobytes())
+        finally:
+            c.close()
+    assert out[1] == out[2]
+    assert np.frombuffer(out[1][0], S.RayHit)["hit"].mean() > 0.2
+
+
 @pytest.mark.parametrize("sort", [0, 1], ids=["unsorted", "sorted"])
 def test_shade_class_sort_forced_on_and_off(luts, sort, monkeypatch):
     """wf_shade's general variants shade a segment grouped by shading class (constants / textured / transmission; HRPT_WF_SHADE_SORT, read at
