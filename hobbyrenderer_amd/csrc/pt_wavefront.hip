@@ -72,6 +72,7 @@ struct WfArgs {
     uint32_t maxLights;        // per-path light-sample slots in the shadow queue
     uint32_t hasMedium;        // scene has thick transmissive materials (medium state travels with the path)
     uint32_t hasStochasticAlpha;
+    uint32_t allOpaque;        // no ForceNonOpaque instance in the scene: closest-hit launches take the OPQ instantiations of wf_extend
     uint32_t refillMin;        // wf_extend refills its idle lanes once at least this many have finished their ray
     uint32_t streamSegments;   // wf_extend moves on to its next segment while rays of the previous one are still in flight
     uint32_t slimShadow;       // slim shadow-queue entries (scenes of the SIMPLE shade variant with one light): sh0{origin, input slot} sh1{N, material}
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 //                                   radiance while the SLP vectoriser was on (138 VGPRs wanted; DESIGN 4 "compiler findings"): re-check the random
 //                                   trait scenes (scripts/parity_campaign.sh) whenever this kernel or the compiler changes. 5 on <SIMPLE>: no gain
 constexpr int kWavesExtendLds = 6, kWavesExtendGlobal = 6, kWavesExtendTwoLevel = 5, kWavesShade = 4;
+#ifndef HRPT_WAVES_EXTEND_LDS_OPAQUE
+#define HRPT_WAVES_EXTEND_LDS_OPAQUE 6
+#endif
+constexpr int kWavesExtendLdsOpaque = HRPT_WAVES_EXTEND_LDS_OPAQUE;
 constexpr uint32_t kRefillMinDefault = 12;
 constexpr uint32_t kShadeRing = 64;        // entries of wf_shade<SIMPLE>'s per-wave ring of parked specular-lobe paths
 constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot without a path (wf_extend<PRIMARY>; 0xFFFFFFFF = miss)
@@ -351,9 +356,12 @@ constexpr uint32_t kNoPathRecord = 0xFFFFFFFEu;     // hit-record code of a slot
 // PRIMARY: bounce 0 of a batch without a raygen pass (WfArgs::primary): the refill derives the ray from the sample index. A separate instantiation:
 // as a run-time branch the extra live state cost the kernel 6 VGPRs and 3 % on EVERY bounce.
 // TL: 0 flat tree, 1 two-level structure with ForceOpaque instances only, 2 two-level with non-opaque instances (candidate re-trace compiled in)
-template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, int TL = 0, bool PRIMARY = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWavesExtendTwoLevel : (LDS_BVH ? kWavesExtendLds : kWavesExtendGlobal)))) void wf_extend(WfArgs a, uint32_t parity)
+// OPQ: no instance of the scene is ForceNonOpaque (closest-hit launches of the flat structure): the candidate rules of TraceRayStandard (lower
+// bound of a re-trace, stochastic-alpha draws) are compiled out -- every hit is committed.
+template <bool LDS_BVH, int DEPTH, int W, bool ANYHIT, int TL = 0, bool PRIMARY = false, bool OPQ = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWavesExtendTwoLevel : (LDS_BVH ? (OPQ ? kWavesExtendLdsOpaque : kWavesExtendLds) : kWavesExtendGlobal)))) void wf_extend(WfArgs a, uint32_t parity)
 {
+    static_assert(!OPQ || (!ANYHIT && !TL), "OPQ: closest hits over the flat structure");
     static_assert(!TL || (!LDS_BVH && !ANYHIT && W == 4), "two-level traversal: global 4-wide tree, closest hit");
     static_assert(!PRIMARY || !ANYHIT, "primary rays are closest-hit rays");
     static_assert(W != kQuantisedTree || (!LDS_BVH && !TL), "quantised nodes: flat tree in global memory");
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
                                 continue;
                             }
                             uint32_t inst = __float_as_uint(ta.w), prim = __float_as_uint(tb.w);
-                            bool ok = !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
+                            const bool ok = OPQ || !lower.have || key_less(lower.t, lower.inst, lower.prim, t, inst, prim);
                             const bool take = ok && (!best.valid || key_less(t, inst, prim, best.t, best.inst, best.prim));      // selects: see the two-level loop above
                             best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v;
                             best.inst = take ? inst : best.inst; best.prim = take ? prim : best.prim; best.tri = take ? first + i : best.tri;
@@ -522,8 +530,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
                 } else if (cur == kTraversalDone) {
                     bool done = true;
                     HRT_PHASE(PH_EXT_FINISH);
-                    if (TL != 1 && best.valid && !(best.opaque & 1u)) HRT_PHASE(PH_EXT_CANDIDATE);
-                    if (TL != 1 && best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
+                    if (!OPQ && TL != 1 && best.valid && !(best.opaque & 1u)) HRT_PHASE(PH_EXT_CANDIDATE);
+                    if (!OPQ && TL != 1 && best.valid && !(best.opaque & 1u) && !candidate_commits(s, best, rng)) {
                         // rejected non-opaque candidate: it becomes the exclusive lower bound of a new closest-hit query
                         lower.have = true; lower.t = best.t; lower.inst = best.inst; lower.prim = best.prim;
                         best.valid = false; tlim = r.tmax; sp = 0;
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TL ? kWa
                         done = false;
                     }
                     if (done) {
-                        if (a.hasStochasticAlpha && rng != rng0) { float4 d = rayD[slot]; d.w = __uint_as_float(rng); rayD[slot] = d; }
+                        if (!OPQ && a.hasStochasticAlpha && rng != rng0) { float4 d = rayD[slot]; d.w = __uint_as_float(rng); rayD[slot] = d; }
                         // hit record: triangle (< 2^29: leaf references hold first << 2) | shading class << 29; 0xFFFFFFFF = miss
                         a.b.hit[slot] = make_float4(best.t, best.u, best.v, __uint_as_float(best.valid ? (best.tri | ((best.opaque >> 1) << 29)) : 0xFFFFFFFFu));
                         if constexpr (TL) a.b.hitInst[slot] = best.inst;
@@ -1283,8 +1291,13 @@ struct Variant { bool lds; int depth; int width; size_t ldsBytes; bool twoLevel 
 
 template <bool L, int D, int W> void launch_extend_t(dim3 g, size_t sh, hipStream_t st, const WfArgs& a, uint32_t parity, bool anyHit)
 {
-    if constexpr (W >= 4) if (a.primary && !anyHit) { launch_rounds((wf_extend<L, D, W, false, false, true>), g, sh, st, a, parity); return; }
+    if constexpr (W >= 4) if (a.primary && !anyHit) {
+        if (a.allOpaque) launch_rounds((wf_extend<L, D, W, false, 0, true, true>), g, sh, st, a, parity);
+        else launch_rounds((wf_extend<L, D, W, false, 0, true>), g, sh, st, a, parity);
+        return;
+    }
     if (anyHit) hipLaunchKernelGGL((wf_extend<L, D, W, true>), g, dim3(kBlock), sh + (size_t)kShadowCandidates * 2 * kBlock * 4, st, a, parity);
+    else if constexpr (W >= 4) { if (a.allOpaque) launch_rounds((wf_extend<L, D, W, false, 0, false, true>), g, sh, st, a, parity); else launch_rounds((wf_extend<L, D, W, false>), g, sh, st, a, parity); }
     else launch_rounds((wf_extend<L, D, W, false>), g, sh, st, a, parity);
 }
 // nonOpaque: 0 = opaque scene, 1 = buffered query inside wf_shadow, 2 = resolve only (after the any-hit pass)
@@ -1595,7 +1608,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     a.b.shadowCnt = (uint32_t*)(base + oShCnt); a.b.radiance = (float4*)(base + oRad);
     a.b.sqO = (float4*)(base + oSqO); a.b.sqD = (float4*)(base + oSqD); a.b.sqId = (uint32_t*)(base + oSqId); a.b.sqCnt = (uint32_t*)(base + oSqCnt); a.b.shVis = (uint32_t*)(base + oShVis); a.b.sqCand = (uint2*)(base + oSqCand);
     a.tilesX = tilesX; a.tilesY = tilesY; a.rect = rect; a.imageWidth = width; a.pixelsPadded = (uint32_t)pixelsPadded;
-    a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u;
+    a.maxLights = maxLights; a.hasMedium = traits.hasMedium ? 1u : 0u; a.hasStochasticAlpha = traits.hasStochasticAlpha ? 1u : 0u; a.allOpaque = traits.hasNonOpaque ? 0u : 1u;
     st.layout.pathRecordBytes = traits.hasMedium ? 80u : 48u; st.layout.maxLights = maxLights;
     a.counters = counters;
     a.refillMin = st.refillMin ? st.refillMin : kRefillMinDefault;
