@@ -33,6 +33,9 @@
 #ifdef HRPT_PHASE_PROFILE
 __device__ unsigned long long g_phaseCounters[128];
 #endif
+#ifdef HRPT_SKY_DEBUG       // diagnostic build: what the miss branch of wf_shade fed into / got out of the sky lookup, first 2048 samples x 16 floats
+__device__ float g_skyDebug[2048 * 16];
+#endif
 
 namespace hrt {
 
@@ -336,9 +339,12 @@ __global__ __launch_bounds__(kBlock) void wf_raygen(WfArgs a, HrptPathTracerCons
 //   wf_extend, tree in global   6   80-82 VGPRs since nodes and triangles are addressed by 32-bit offsets (84 and +2 % at 6 waves before): config 4 -2 %
 //   wf_extend<TL>               5   100-117 VGPRs: a few spilled registers buy the fifth wave (-4 %); with the SLP vectoriser on the same
 //                                   setting doubled the kernel's time (128 VGPRs wanted)
-//   wf_shade, any variant       4   general single-light variant: 129 VGPRs wanted, -14 % against 3 waves. The same setting produced wrong sky
-//                                   radiance while the SLP vectoriser was on (138 VGPRs wanted; DESIGN 4 "compiler findings"): re-check the random
-//                                   trait scenes (scripts/parity_campaign.sh) whenever this kernel or the compiler changes. 5 on <SIMPLE>: no gain
+//   wf_shade, any variant       4   general single-light variant: 121-129 VGPRs wanted, -14 % against 3 waves. The same setting produced wrong sky
+//                                   radiance while the SLP vectoriser was on (138 VGPRs wanted). Root cause (round 3, profiles/r03_wrong_sky_isa_evidence.txt):
+//                                   a backend bug under register pressure -- the hoisted constant of mie_phase was kept alive through a live-range-split
+//                                   copy placed in ONE arm of a divergent if/else, so the lanes of the other arm restored garbage. The guards: the random
+//                                   trait scenes of the GPU suite (seed 1 fails on that build) and tests/test_kernel_resources.py (no scratch, <= 128
+//                                   VGPRs). Re-check both whenever this kernel, the flags or the compiler change. 5 waves on <SIMPLE>: no gain
 constexpr int kWavesExtendLds = 6, kWavesExtendGlobal = 6, kWavesExtendTwoLevel = 5, kWavesShade = 4;
 #ifndef HRPT_WAVES_EXTEND_LDS_OPAQUE
 #define HRPT_WAVES_EXTEND_LDS_OPAQUE 6
@@ -879,6 +885,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWavesSh
                 } else {
                     miss_sky(s, cb, ps, bounce);   // ps.radiance = throughput * sky
                     addRadiance = true; add = ps.radiance;
+#ifdef HRPT_SKY_DEBUG
+                    if (smp < 2048u && bounce == 0) {
+                        float* g = g_skyDebug + smp * 16u;
+                        g[0] = ps.ray.o.x; g[1] = ps.ray.o.y; g[2] = ps.ray.o.z; g[3] = ps.ray.d.x; g[4] = ps.ray.d.y; g[5] = ps.ray.d.z;
+                        g[6] = cb.m_SunDirection[0]; g[7] = cb.m_SunDirection[1]; g[8] = cb.m_SunDirection[2]; g[9] = s.lights[0].m_Intensity;
+                        g[10] = ps.radiance.x; g[11] = ps.radiance.y; g[12] = ps.radiance.z; g[13] = ps.throughput.x; g[14] = ps.throughput.y; g[15] = ps.throughput.z;
+                    }
+#endif
                 }
                 if constexpr (PRIMARY) {
                     // first term of the sample (a padding slot gets a zero nobody reads): 0 + term, stored (no wf_raygen zeroed sampleRadiance; the addition keeps the sign of a -0 term as the
@@ -1472,6 +1486,9 @@ void wavefront_collect_timing(WavefrontState& st)
     st.eventsUsed = 0;
 }
 
+#ifdef HRPT_SKY_DEBUG
+extern "C" int hrpt_sky_debug_read(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_skyDebug), sizeof(float) * 2048 * 16) == hipSuccess ? 0 : -3; }
+#endif
 #ifdef HRPT_PHASE_PROFILE
 // reads (and zeroes) the phase counters of this library build
 extern "C" int hrpt_phase_profile_read(unsigned long long* out128)
