@@ -59,7 +59,8 @@ int main(int argc, char** argv)
         proj.aspectRatio = (float)width / (float)height;
     }
     s.m_Camera.SetProjection(proj);
-    if (GenerateAtmosphereLuts(s, 0) != HRPT_OK) { std::fprintf(stderr, "LUT generation failed\n"); return 1; }
+    // the Bruneton tables are needed by the upload only (four scattering orders: ~0.1 s on the GPU the context is about to use, ~40 s on host threads)
+    if (!noGpu && GenerateAtmosphereLuts(s, 0) != HRPT_OK) { std::fprintf(stderr, "LUT generation failed\n"); return 1; }
     g_Renderer.m_PathTracerMaxBounces = bounces;
 
     HrptContext* ctx = nullptr;

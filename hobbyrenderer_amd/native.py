@@ -30,7 +30,7 @@ EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
     "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_acceleration_structure", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
-    "hrpt_precompute_atmosphere",
+    "hrpt_precompute_atmosphere", "hrpt_precompute_atmosphere_ex", "hrpt_atmosphere_pass",
 ]
 
 lib.hrpt_create.argtypes = [C.POINTER(S.DeviceDesc), C.POINTER(C.c_void_p)]
@@ -71,6 +71,8 @@ lib.hrpt_set_exposure.argtypes = [C.c_void_p, C.c_float]
 lib.hrpt_halton.argtypes = [C.c_uint32, C.c_uint32]
 lib.hrpt_halton.restype = C.c_float
 lib.hrpt_precompute_atmosphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.hrpt_precompute_atmosphere_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+lib.hrpt_atmosphere_pass.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_int, C.c_int]
 
 
 class HrptError(RuntimeError):
@@ -79,14 +81,48 @@ class HrptError(RuntimeError):
         self.code = code
 
 
-def precompute_atmosphere(nthreads=0):
-    """Stand-ins for bin/bruneton/*.dat (src/CommonResources.cpp:519-569): float32 RGBA tables."""
+ATMOSPHERE_ORDERS = 4        # scattering orders of the default tables (Bruneton's demo value; the reference's own count is unknown)
+
+
+def _atmosphere_cache_path(orders):
+    """Cache file of the tables for this producer source: hobbyrenderer_amd/.cache/ (git-ignored; it travels to the GPU box like the built
+    libraries do). The key covers the producer and the arithmetic header, so an edit of either invalidates it."""
+    import hashlib
+    h = hashlib.sha1()
+    for rel in (("csrc", "atmosphere_precompute.cpp"), ("..", "include", "hobbyrt", "detmath.h")):
+        with open(os.path.join(_HERE, *rel), "rb") as f:
+            h.update(f.read())
+    return os.path.join(_HERE, ".cache", f"atmosphere_o{orders}_{h.hexdigest()[:12]}.npz")
+
+
+def precompute_atmosphere(nthreads=0, orders=ATMOSPHERE_ORDERS, device=-2, cache=True):
+    """Stand-ins for bin/bruneton/*.dat (src/CommonResources.cpp:519-569): float32 RGBA tables (transmittance 64 x 256, scattering
+    32 x 128 x 256, irradiance 16 x 64) with `orders` scattering orders (csrc/atmosphere_precompute.cpp). device: -1 host threads, >= 0 that
+    GPU, -2 the current GPU when there is one. The result does not depend on the executor (bit-identical; tests/test_atmosphere.py), so it
+    is cached on disk: four orders take ~40 s on 8 host threads and ~0.1 s on the GPU."""
+    path = _atmosphere_cache_path(orders) if cache else None
+    if path and os.path.exists(path):
+        try:
+            with np.load(path) as z:
+                t, s, i = z["transmittance"], z["scattering"], z["irradiance"]
+            if t.shape == S.LUT_TRANSMITTANCE_SHAPE and s.shape == S.LUT_SCATTERING_SHAPE and i.shape == S.LUT_IRRADIANCE_SHAPE:
+                return t, s, i
+        except (OSError, ValueError, KeyError):
+            pass
     t = np.zeros(S.LUT_TRANSMITTANCE_SHAPE, np.float32)
     s = np.zeros(S.LUT_SCATTERING_SHAPE, np.float32)
     i = np.zeros(S.LUT_IRRADIANCE_SHAPE, np.float32)
-    rc = lib.hrpt_precompute_atmosphere(t.ctypes.data, s.ctypes.data, i.ctypes.data, nthreads)
+    rc = lib.hrpt_precompute_atmosphere_ex(t.ctypes.data, s.ctypes.data, i.ctypes.data, orders, nthreads, device)
     if rc != 0:
-        raise HrptError(rc, "hrpt_precompute_atmosphere")
+        raise HrptError(rc, "hrpt_precompute_atmosphere_ex")
+    if path:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, transmittance=t, scattering=s, irradiance=i)
+            os.replace(tmp, path)
+        except OSError:
+            pass
     return t, s, i
 
 

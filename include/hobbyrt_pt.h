@@ -457,11 +457,22 @@ int  hrpt_selftest_unorm8(HrptContext* ctx, float* out512);
  * produce the same constants: Halton (src/Utilities.cpp:67-79) and the CB fill (:58-75). */
 float hrpt_halton(uint32_t index, uint32_t base);
 
-/* Host-side producer of stand-ins for bin/bruneton/{transmittance,scattering,irradiance}.dat, which the
- * reference loads (src/CommonResources.cpp:519-569) but does not ship: raw float32 RGBA tables of
- * 256*64, 256*128*32 and 64*16 texels from the constants of src/shaders/Atmosphere.hlsli:41-75
- * (transmittance + single scattering; irradiance is zero-filled and may be NULL). No GPU needed. */
+/* Producer of stand-ins for bin/bruneton/{transmittance,scattering,irradiance}.dat, which the reference loads
+ * (src/CommonResources.cpp:519-569) but does not ship: raw float32 RGBA tables of 256*64, 256*128*32 and 64*16 texels from
+ * the constants of src/shaders/Atmosphere.hlsli:41-75, following Bruneton's 2017 precomputation: transmittance, single
+ * scattering, and `orders` - 1 further scattering orders (scattering density, indirect ground irradiance, multiple
+ * scattering; ground albedo 0.1). irradiance may be NULL. hrpt_precompute_atmosphere computes 4 orders (Bruneton's demo value;
+ * what the reference's files hold is unknown) on the current HIP device when there is one, else on host threads;
+ * the _ex form chooses: orders 1..8 (1 = single scattering only, zero irradiance table), device -1 = host threads, >= 0 = that HIP
+ * device, -2 = automatic. The tables are bit-identical whichever executor computed them (one __host__ __device__ source in the
+ * arithmetic of hobbyrt/detmath.h). Four orders: ~0.1 s on an MI355X, ~40 s on 8 host threads. */
 int  hrpt_precompute_atmosphere(float* transmittance, float* scattering, float* irradiance, int nthreads);
+int  hrpt_precompute_atmosphere_ex(float* transmittance, float* scattering, float* irradiance, int orders, int nthreads, int device);
+/* Test hook: texels [first, first + count) of one pass (3 scattering density, 4 indirect irradiance, 5 multiple scattering) of order `order`
+ * from tables in host memory (3 floats per texel; transmittance / scattering4: 4), by host threads (device < 0) or on HIP device `device`. */
+int  hrpt_atmosphere_pass(int pass, int order, uint32_t first, uint32_t count, const float* transmittance, const float* deltaIrradiance,
+                          const float* deltaRayleigh, const float* deltaMie, const float* deltaDensity, const float* deltaMultiple,
+                          float* scattering4, float* out3, int nthreads, int device);
 
 #ifdef __cplusplus
 } /* extern "C" */
