@@ -1142,9 +1142,89 @@ HRT_DEV f3 normal_with_tbn(float nx, float ny, f3 normal, f3 tangent, float tang
     return normalize(o);
 }
 // GetPBRAttributes, RaytracingCommon.hlsli:252-296
+// The four material textures of a hit fetched TOGETHER (GetPBRAttributes, RaytracingCommon.hlsli:252-296). Sampled one after the other, every texture
+// is a chain of dependent round trips -- descriptor, then the four texels of its bilinear footprint, then (sRGB formats) the linearisation table --
+// and a hit with three maps waits for nine of them in a row; wf_shade on textured scenes spends 69 % of its wave cycles waiting
+// (profiles/r02_pmc_config4.txt). Here all descriptors are requested first, then all sixteen texels (unused slots read texel 0 of a valid
+// texture: no divergent branch between the requests), and only then the filtering arithmetic runs, texture by texture, exactly as
+// sample_texture_level does it: same operations, same order, same bits. Only for 8-bit formats (RGBA8_UNORM / RGBA8_SRGB, what stb-decoded and
+// block-decoded images arrive as) at level 0; anything else takes the one-by-one path below.
+#ifndef HRPT_NO_BATCHED_TEXTURES
+struct TexSlot { const uint32_t* texels; uint32_t format, sampler; int w, h; bool on; };
+HRT_DEV bool pbr_textures_batched(const SceneView& s, f2 uv, const HrptMaterialConstants& m, uint32_t texFlags, f4 (&out)[4])
+{
+    if (s.textureCount == 0u) return false;
+    const uint32_t index[4] = { m.m_AlbedoTextureIndex, m.m_RoughnessMetallicTextureIndex, m.m_EmissiveTextureIndex, m.m_NormalTextureIndex };
+    const uint32_t sampler[4] = { m.m_AlbedoSamplerIndex, m.m_RoughnessSamplerIndex, m.m_EmissiveSamplerIndex, m.m_NormalSamplerIndex };
+    const uint32_t bit[4] = { HRPT_TEXFLAG_ALBEDO, HRPT_TEXFLAG_ROUGHNESS_METALLIC, HRPT_TEXFLAG_EMISSIVE, HRPT_TEXFLAG_NORMAL };
+    TexSlot t[4];
+    bool simple = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {             // round 1: the descriptors
+        const bool want = (texFlags & bit[k]) != 0u && index[k] < s.textureCount;
+        const GpuTexture& g = s.textures[want ? index[k] : 0u];
+        t[k].texels = reinterpret_cast<const uint32_t*>(g.texels); t[k].format = g.format; t[k].w = (int)g.w; t[k].h = (int)g.h; t[k].sampler = sampler[k];
+        t[k].on = want && g.texels != nullptr;
+        // (a flagged texture whose index is out of range or whose texels are missing samples as zero, as sample_texture does)
+        simple = simple && (!t[k].on || g.format == HRPT_TEXTURE_FORMAT_RGBA8_UNORM || g.format == HRPT_TEXTURE_FORMAT_RGBA8_SRGB);
+    }
+    if (!simple) return false;
+    uint32_t word[4][4]; float tx[4], ty[4]; bool point[4];
+    const uint32_t* safe = reinterpret_cast<const uint32_t*>(s.textures);      // readable, whatever it holds: the slot's result is discarded
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {             // round 2: the footprints (sample_texture_level's address arithmetic) and the sixteen texel requests
+        const bool wrap = (t[k].sampler <= 5u) ? ((t[k].sampler & 1u) != 0) : false;
+        point[k] = (t[k].sampler == 2u || t[k].sampler == 3u);
+        const int lw = t[k].on ? t[k].w : 1, lh = t[k].on ? t[k].h : 1;
+        float fx = uv.x * (float)lw, fy = uv.y * (float)lh;
+        if (!point[k]) { fx = fx - 0.5f; fy = fy - 0.5f; }
+        const float ix = hrt_floor(fx), iy = hrt_floor(fy);
+        tx[k] = point[k] ? 0.0f : fx - ix; ty[k] = point[k] ? 0.0f : fy - iy;
+        const int x0 = wrap_i((int)ix, lw, wrap), x1 = wrap_i((int)ix + 1, lw, wrap), y0 = wrap_i((int)iy, lh, wrap), y1 = wrap_i((int)iy + 1, lh, wrap);
+        const uint32_t* base = t[k].on ? t[k].texels : safe;
+        const uint32_t r0 = (uint32_t)y0 * (uint32_t)lw, r1 = (uint32_t)y1 * (uint32_t)lw;
+        word[k][0] = base[t[k].on ? r0 + (uint32_t)x0 : 0u]; word[k][1] = base[t[k].on ? r0 + (uint32_t)x1 : 0u];
+        word[k][2] = base[t[k].on ? r1 + (uint32_t)x0 : 0u]; word[k][3] = base[t[k].on ? r1 + (uint32_t)x1 : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {             // round 3: decode + filter, texture by texture
+        f4 c[4];
+        const bool srgb = t[k].format == HRPT_TEXTURE_FORMAT_RGBA8_SRGB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = word[k][j];
+            if (srgb) { c[j].x = kSrgbToLinear[p & 255u]; c[j].y = kSrgbToLinear[(p >> 8) & 255u]; c[j].z = kSrgbToLinear[(p >> 16) & 255u]; }
+            else { c[j].x = unorm8_to_float(p & 255u); c[j].y = unorm8_to_float((p >> 8) & 255u); c[j].z = unorm8_to_float((p >> 16) & 255u); }
+            c[j].w = unorm8_to_float(p >> 24);
+        }
+        f4 r;
+        if (point[k]) r = c[0];
+        else { const f4 a = lerp4(c[0], c[1], tx[k]), b = lerp4(c[2], c[3], tx[k]); r = lerp4(a, b, ty[k]); }
+        if (!t[k].on) r.x = r.y = r.z = r.w = 0.0f;
+        out[k] = r;
+    }
+    return true;
+}
+#endif
 HRT_DEV Pbr pbr_attributes(const SceneView& s, const SurfaceAttr& a, const HrptMaterialConstants& m, uint32_t texFlags)
 {
     Pbr p;
+#ifndef HRPT_NO_BATCHED_TEXTURES
+    f4 tex[4];
+    if (texFlags != 0u && pbr_textures_batched(s, a.uv, m, texFlags, tex)) {
+        HRT_PHASE(PH_SHADE_TEX);
+        p.baseColor = mk3(m.m_BaseColor); p.alpha = m.m_BaseColor[3];
+        if (texFlags & HRPT_TEXFLAG_ALBEDO) { p.baseColor = p.baseColor * mk3(tex[0].x, tex[0].y, tex[0].z); p.alpha *= tex[0].w; }
+        p.roughness = m.m_RoughnessMetallic[0]; p.metallic = m.m_RoughnessMetallic[1];
+        if (texFlags & HRPT_TEXFLAG_ROUGHNESS_METALLIC) { p.roughness = tex[1].y; p.metallic = tex[1].z; }
+        p.roughness = hrt_max(p.roughness, 0.04f);
+        p.emissive = mk3(m.m_EmissiveFactor);
+        if (texFlags & HRPT_TEXFLAG_EMISSIVE) p.emissive = p.emissive * mk3(tex[2].x, tex[2].y, tex[2].z);
+        if (texFlags & HRPT_TEXFLAG_NORMAL) p.normal = normal_with_tbn(tex[3].x, tex[3].y, a.worldNormal, a.worldTangent, a.tangentSign);
+        else p.normal = normalize(a.worldNormal);
+        return p;
+    }
+#endif
     p.baseColor = mk3(m.m_BaseColor); p.alpha = m.m_BaseColor[3];
     if (texFlags & HRPT_TEXFLAG_ALBEDO) {
         HRT_PHASE(PH_SHADE_TEX);
