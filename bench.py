@@ -277,11 +277,14 @@ def main(argv=None):
     for c in lanes:
         c.reset_stats()
         c.synchronize()
+    if frames is not None:
+        frames.comm_wait_ms()                                   # drop the waits of the warm-up steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    comm_wait_ms = frames.comm_wait_ms() / max(1, args.steps) if frames is not None else 0.0
 
     class _Sum:                                               # ray counters of all lanes of this rank
         closestRays = sum(int(c.stats().closestRays) for c in lanes)
@@ -329,10 +332,13 @@ def main(argv=None):
     per_rank = None
     if sharded:
         mine = torch.tensor([float(pst.lastRenderMs) if prof_steps else 0.0, my_elapsed / args.steps * 1e3,
-                             frames.gather_ms() if frames is not None else 0.0], dtype=torch.float64, device=red_dev)
+                             frames.gather_ms() if frames is not None else 0.0, comm_wait_ms], dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": i, "render_ms_alone": float(t[0]), "step_ms": float(t[1]), "gather_resolve_ms": float(t[2])} for i, t in enumerate(allr)]
+        # render_ms_alone: device time of one hrpt_render of the rank's share with nothing else on the GPU; step_ms: the rank's own wall time per step in
+        # the timed region; gather_resolve_ms: comm-stream work (all-gather + re-assembly + resolve) of one frame; comm_wait_ms_per_step: what the lanes'
+        # streams waited for that work per step (0 = fully hidden behind the next renders)
+        per_rank = [{"rank": i, "render_ms_alone": float(t[0]), "step_ms": float(t[1]), "gather_resolve_ms": float(t[2]), "comm_wait_ms_per_step": float(t[3])} for i, t in enumerate(allr)]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -354,6 +360,9 @@ def main(argv=None):
             result["one_frame_in_flight"] = {"ms_per_step": one_at_a_time_ms, "value": total_rays / args.steps / one_at_a_time_ms / 1e3, "unit": "Mrays/s"}
         if per_rank is not None:
             result["per_rank"] = per_rank
+            steps_ms = [r["step_ms"] for r in per_rank]
+            result["rank_balance"] = {"slowest_over_mean_step": max(steps_ms) / (sum(steps_ms) / len(steps_ms)),
+                                      "slowest_over_mean_render_alone": (max(r["render_ms_alone"] for r in per_rank) / max(1e-9, sum(r["render_ms_alone"] for r in per_rank) / len(per_rank)))}
         # ---- cpu_baseline + n/t counters: the oracle on a bounded sample of THIS config (N = 1 only)
         model = None
         if world == 1 and not args.no_cpu_baseline:

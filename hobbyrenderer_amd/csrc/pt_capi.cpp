@@ -630,7 +630,8 @@ static int render_impl(HrptContext* c, const HrptFrameParams* p)
     HIP_TRY(c, hipSetDevice(c->device));
 
     bool wavefront = (p->flags & HRPT_FRAME_MEGAKERNEL) == 0 && wavefront_supports(c->view, p->constants);
-    if (!wavefront && c->view.instances) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: the megakernel does not traverse the two-level structure (hrpt_set_acceleration_structure)");
+    if (!wavefront && c->view.instances && c->traits.twoLevelStackNeed > 64u)
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_render: this two-level structure is deeper than the validation megakernel's 64-entry stack");
     if (!wavefront && (p->flags & HRPT_FRAME_MEGAKERNEL) == 0) c->megakernelFallbacks++;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (wavefront) {
@@ -811,8 +812,8 @@ int hrpt_trace_rays(HrptContext* c, const HrptRay* rays, HrptRayHit* hits, uint6
     if (!rays || !hits) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: null array");
     if ((flags & 0xFFu) > HRPT_RAYS_SHADOW || (flags & ~(0xFFu | HRPT_RAYS_DEVICE_POINTERS | HRPT_RAYS_THREAD_PER_RAY))) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: unknown flags");
     if (count > (1ull << 31)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: too many rays in one call");
-    if (c->view.instances && ((flags & HRPT_RAYS_THREAD_PER_RAY) || !wavefront_trace_rays_supported(c->traits)))
-        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: the thread-per-ray kernel does not traverse the two-level structure (hrpt_set_acceleration_structure)");
+    if (c->view.instances && ((flags & HRPT_RAYS_THREAD_PER_RAY) || !wavefront_trace_rays_supported(c->traits)) && c->traits.twoLevelStackNeed > 64u)
+        return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_trace_rays: this two-level structure is deeper than the thread-per-ray kernel's 64-entry stack");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool shadow = (flags & 0xFFu) == HRPT_RAYS_SHADOW;
     // the persistent refilling traversal kernel (pt_wavefront.hip wf_trace_rays); the thread-per-ray kernel stays as the fallback for trees

@@ -3,6 +3,8 @@
 // dispatch of the reference (8x8 groups -> here 64-lane waves over 8x8 pixel tiles). It exists to prove
 // struct layouts, RNG streams, LUT sampling, the BVH and the shading stages bit-for-bit against the CPU
 // oracle; the wavefront pipeline (pt_wavefront.hip) is the production path and reuses the same stages.
+#include <type_traits>
+
 #include "pt_kernels.h"
 #include "pt_path.h"
 
@@ -22,6 +24,10 @@ HRT_DEV unsigned long long wave_sum(unsigned int v)
     return x;
 }
 
+// TL: the scene holds the two-level structure (SceneView::instances): the same shader over closest_two_level / shadow_query_two_level
+// (pt_device.h, pt_path.h), so that the two-level kernels of the wavefront pipeline keep the wavefront == megakernel cross-check every other
+// path has. Private 64-entry stack: scenes whose two-level stack need is larger are refused by hrpt_render.
+template <bool TL>
 __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerConstants cb, float4* __restrict__ accumulation,
                                                     float4* __restrict__ output, uint32_t imageWidth, TileRect rect,
                                                     DeviceCounters* counters)
@@ -33,7 +39,8 @@ __global__ __launch_bounds__(64) void pt_megakernel(SceneView s, HrptPathTracerC
     unsigned int nClosest = 0, nShadow = 0;
 
     if (active) {
-        GlobalBvh bvh; bvh.nodes = s.nodes; bvh.tris = s.tris;
+        typename std::conditional<TL, GlobalBvhTl, GlobalBvh>::type bvh;
+        if constexpr (TL) { bvh.nodes = s.nodes4; bvh.tris = s.tris; bvh.instances = s.instances; } else { bvh.nodes = s.nodes; bvh.tris = s.tris; }
         PrivateStack stack;
         PathState ps; init_path(ps, cb, px, py);
         int maxBounces = (int)cb.m_MaxBounces;
@@ -128,7 +135,8 @@ hipError_t launch_megakernel(const SceneView& scene, const HrptPathTracerConstan
 {
     if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0 || rect.columns() == 0) return hipSuccess;
     dim3 grid(rect.columns(), (rect.y1 - rect.y0 + 7) / 8, 1);
-    hipLaunchKernelGGL(pt_megakernel, grid, dim3(64, 1, 1), 0, stream, scene, constants, accumulation, output, imageWidth, rect, counters);
+    if (scene.instances) hipLaunchKernelGGL(pt_megakernel<true>, grid, dim3(64, 1, 1), 0, stream, scene, constants, accumulation, output, imageWidth, rect, counters);
+    else hipLaunchKernelGGL(pt_megakernel<false>, grid, dim3(64, 1, 1), 0, stream, scene, constants, accumulation, output, imageWidth, rect, counters);
     return hipGetLastError();
 }
 
@@ -294,14 +302,15 @@ hipError_t launch_bvh_check(const SceneView& scene, unsigned long long* violatio
 // Stand-alone ray queries over the scene's acceleration structure: TraceRayStandard (RaytracingCommon.hlsli:138-198) and
 // CalculateRTShadow<true> (CommonLighting.hlsli:380-496) for callers other than the path tracer (the reference's DDGI probe trace,
 // ray-traced shadows and BRDF ray tracing share exactly these two includes). One thread per ray, 2-wide tree, private stack.
-template <bool SHADOW>
+template <bool SHADOW, bool TL>
 __global__ __launch_bounds__(256) void pt_trace_rays_kernel(SceneView s, const HrptRay* __restrict__ rays, HrptRayHit* __restrict__ hits, uint64_t count)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     HrptRay r = rays[i];
     HrptRayHit out; out.t = 0.0f; out.u = 0.0f; out.v = 0.0f; out.instance = 0; out.primitive = 0; out.hit = 0; out.rng = r.rng; out.pad = 0;
-    GlobalBvh bvh; bvh.nodes = s.nodes; bvh.tris = s.tris;
+    typename std::conditional<TL, GlobalBvhTl, GlobalBvh>::type bvh;
+    if constexpr (TL) { bvh.nodes = s.nodes4; bvh.tris = s.tris; bvh.instances = s.instances; } else { bvh.nodes = s.nodes; bvh.tris = s.tris; }
     PrivateStack stack;
     f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
     const bool finite = d.x == d.x && d.y == d.y && d.z == d.z && o.x == o.x && o.y == o.y && o.z == o.z;
@@ -320,8 +329,11 @@ hipError_t launch_trace_rays(const SceneView& scene, const HrptRay* rays, HrptRa
 {
     if (count == 0) return hipSuccess;
     dim3 grid((unsigned)((count + 255) / 256));
-    if (shadow) hipLaunchKernelGGL((pt_trace_rays_kernel<true>), grid, dim3(256), 0, stream, scene, rays, hits, count);
-    else hipLaunchKernelGGL((pt_trace_rays_kernel<false>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+    if (scene.instances) {
+        if (shadow) hipLaunchKernelGGL((pt_trace_rays_kernel<true, true>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+        else hipLaunchKernelGGL((pt_trace_rays_kernel<false, true>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+    } else if (shadow) hipLaunchKernelGGL((pt_trace_rays_kernel<true, false>), grid, dim3(256), 0, stream, scene, rays, hits, count);
+    else hipLaunchKernelGGL((pt_trace_rays_kernel<false, false>), grid, dim3(256), 0, stream, scene, rays, hits, count);
     return hipGetLastError();
 }
 

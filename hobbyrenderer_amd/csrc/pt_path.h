@@ -72,9 +72,11 @@ HRT_DEV bool trace_standard(const SceneView& s, const BVH& bvh, const Ray& ray, 
 {
     HitKey lower; lower.have = false; lower.t = 0.0f; lower.inst = 0; lower.prim = 0;
     for (;;) {
-        Hit h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+        Hit h;
+        if constexpr (BVH::kTwoLevel) h = closest_two_level(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
+        else h = closest_any(bvh, s.rootLeaf, s.nodeCount, ray, lower, stack);
         if (!h.valid) return false;
-        if (h.opaque || candidate_commits(s, h, rng)) { out = h; return true; }
+        if ((h.opaque & 1u) || candidate_commits(s, h, rng)) { out = h; return true; }
         lower.have = true; lower.t = h.t; lower.inst = h.inst; lower.prim = h.prim;
     }
 }

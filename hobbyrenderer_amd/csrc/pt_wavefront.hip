@@ -1444,7 +1444,7 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     }
     const size_t ldsBytes = stackBytes + (lds ? bvhBytes : 0);
     if (twoLevel) {
-        const dim3 g(grid); const size_t sl = ldsBytes;     // (no candidate columns: every instance is opaque)
+        const dim3 g(grid); const size_t sl = ldsBytes;     // (no candidate columns: visibility queries over non-opaque instances re-trace behind every candidate)
         if (shadow) { if (depth <= 16) launch_rounds((wf_trace_rays<false, 16, 4, true, true>), g, sl, stream, a); else if (depth <= 32) launch_rounds((wf_trace_rays<false, 32, 4, true, true>), g, sl, stream, a); else launch_rounds((wf_trace_rays<false, 64, 4, true, true>), g, sl, stream, a); }
         else { if (depth <= 16) launch_rounds((wf_trace_rays<false, 16, 4, false, true>), g, sl, stream, a); else if (depth <= 32) launch_rounds((wf_trace_rays<false, 32, 4, false, true>), g, sl, stream, a); else launch_rounds((wf_trace_rays<false, 64, 4, false, true>), g, sl, stream, a); }
     } else
@@ -1678,7 +1678,9 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
     int shadowMode = (!vS.lds && unevenRays) ? kShadowResolve : selfMode;
     if (st.shadowPath == 1) shadowMode = selfMode;
     if (st.shadowPath == 2 && (traits.hasNonOpaque || maxLights > 1)) shadowMode = kShadowResolve;
-    if (traits.twoLevelStackNeed) shadowMode = kShadowOpaque;      // every instance of a two-level scene is opaque; no any-hit pass over that structure
+    // two-level scenes: wf_shadow traverses itself (no any-hit pass over that structure); TL = 1 instantiations when every instance is opaque, TL = 2
+    // (buffered candidates of non-opaque instances, shadow_query_two_level_buffered) otherwise -- launch_shadow picks by Variant::twoLevelCandidates
+    if (traits.twoLevelStackNeed) shadowMode = kShadowOpaque;
     // any-hit pass over the shadow rays (same kernel family as vE). wf_extend<ANYHIT> always carves its candidate columns out of LDS
     // (launch_extend_t adds them to the launch), opaque scene or not, so the budget check must count them too.
     const Variant vA = pick(forced ? forced : 4, (size_t)kShadowCandidates * 2 * kBlock * 4, kExtendLdsStack);

@@ -133,6 +133,8 @@ class PipelinedFrames:
             # device time of the comm-stream work (all-gather + re-assembly + resolve) of the frame in each slot
             self.gather_begin = [torch.cuda.Event(enable_timing=True) for _ in range(self.slots)]
             self.gather_end = [torch.cuda.Event(enable_timing=True) for _ in range(self.slots)]
+            # what a lane's stream actually waited for the comm stream (a slot coming round again before its gather + resolve were done)
+            self.wait_pairs = []
 
     def submit(self):
         """Enqueue one frame; returns the slot (0/1) whose `gathered`/`output` images will hold it."""
@@ -144,7 +146,11 @@ class PipelinedFrames:
             with torch.cuda.stream(main):
                 self.render_band[lane](self.y0, self.y1)
                 if self.frame >= self.slots:
+                    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    w0.record(main)
                     main.wait_event(self.delivered[s])      # slot s is free again once the gather + resolve of the frame that used it are done
+                    w1.record(main)
+                    self.wait_pairs.append((w0, w1))
                 self.staging[s].copy_(self.band_view[lane])  # the only payload that crosses xGMI
                 self.rendered[s].record(main)
             with torch.cuda.stream(self.comm):
@@ -177,6 +183,15 @@ class PipelinedFrames:
             return 0.0
         s = (self.frame - 1) % self.slots
         return float(self.gather_begin[s].elapsed_time(self.gather_end[s]))
+
+    def comm_wait_ms(self):
+        """Total device time the lanes' streams spent waiting for the comm stream since the last call (after the streams were synchronised):
+        0 when every all-gather + resolve hid behind the next renders."""
+        if not self.gpu:
+            return 0.0
+        total = sum(float(a.elapsed_time(b)) for a, b in self.wait_pairs)
+        self.wait_pairs = []
+        return total
 
     def finish(self):
         """Make the current stream wait for every submitted frame (host synchronisation stays with the caller)."""

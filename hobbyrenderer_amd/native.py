@@ -242,7 +242,7 @@ class PathTracerContext:
 
     def set_acceleration_structure(self, structure):
         """S.ACCEL_AUTO (default), S.ACCEL_FLAT (one world-space tree) or S.ACCEL_TWO_LEVEL (a tree per distinct mesh + a tree over the instances;
-        opaque scenes only, otherwise the flat tree is built -- build_info().structure tells); used by the next upload_scene."""
+        opaque and non-opaque instances alike; a scene with a singular instance matrix is built flat -- build_info().structure tells); used by the next upload_scene."""
         self._check(lib.hrpt_set_acceleration_structure(self._h, int(structure)))
 
     def update_instances(self, instances, first=0):

@@ -337,9 +337,10 @@ int  hrpt_get_build_info(HrptContext* ctx, HrptBuildInfo* out);
  * object-space tree per distinct mesh plus a tree over the instances: memory grows with distinct triangles + instances, hrpt_update_instances rebuilds only the small instance tree (the
  * reference's per-frame TLAS build), traversal pays a ray transform per visited instance. Radiance is identical: hits are still
  * decided in world space on the world-space vertices the flat upload would produce, non-opaque instances (MASK / BLEND / transmissive
- * materials) included: their candidates are visited in the same front-to-back order. Two-level runs on the wavefront pipeline and the
- * persistent ray-query kernel only (HRPT_FRAME_MEGAKERNEL, HRPT_RAYS_THREAD_PER_RAY and hrpt_selftest_bvh answer HRPT_ERR_INVALID_ARGUMENT
- * on such a scene). A scene that cannot be held
+ * materials) included: their candidates are visited in the same front-to-back order. Every render / query entry point traverses it: the wavefront
+ * pipeline, the validation megakernel (HRPT_FRAME_MEGAKERNEL) and both ray-query kernels (the last two with a private 64-entry stack: deeper
+ * structures answer HRPT_ERR_INVALID_ARGUMENT there); hrpt_selftest_bvh is a flat-structure check and answers HRPT_ERR_INVALID_ARGUMENT
+ * on such a scene. A scene that cannot be held
  * in this form (an instance whose world matrix has no inverse, now or after a later hrpt_update_instances) is built flat whatever was
  * asked -- HrptBuildInfo::structure tells. AUTO: two-level when the scene has at least 2 M world triangles (16 M if any instance is non-opaque: measured cross-over) and at least 8
  * instances per distinct mesh on average (measured on MI355X, opaque spheres / cylinders of ~400 triangles, 1920x1080, 8 spp, 4 bounces:

@@ -335,8 +335,43 @@ def test_ray_queries_over_a_two_level_scene_with_non_opaque_instances(luts):
     assert np.array_equal(vf["t"].view(np.uint32), vt["t"].view(np.uint32))
 
 
-def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
+@pytest.mark.parametrize("kind", ["opaque-three-lights", "mask+glass"])
+def test_megakernel_and_thread_per_ray_walk_the_two_level_structure(luts, kind):
+    """The validation megakernel (HRPT_FRAME_MEGAKERNEL) and the thread-per-ray query kernel (HRPT_RAYS_THREAD_PER_RAY) traverse the two-level
+    structure too (closest_two_level / shadow_query_two_level with a private stack): wavefront == megakernel on a two-level scene, and the
+    persistent ray-query kernel == the thread-per-ray kernel -- the cross-checks every other path has. hrpt_selftest_bvh stays a flat-structure
+    check (its boxes are per mesh, in object space) and says so."""
     from hobbyrenderer_amd.native import PathTracerContext, HrptError
+    n = 8
+    sc = instanced_scene(luts, n, seed=23, masked="mask" in kind, glass="glass" in kind, lights="three" if "three" in kind else "sun")
+    view, pos = _camera(96, 64, n)
+    cb = scenes.fill_constants(view, pos, sc, 0, 5)
+    rng = np.random.default_rng(8)
+    rays = np.zeros(6000, S.Ray)
+    rays["origin"] = (rng.random((len(rays), 3)).astype(np.float32) - np.float32(0.5)) * np.float32([1.6 * n, 5.0, 1.6 * n]) + np.float32([0, 2.5, 0])
+    d = rng.normal(size=(len(rays), 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays["direction"] = d; rays["tmax"] = 1e10; rays["rng"] = rng.integers(0, 2 ** 32, len(rays), dtype=np.uint64).astype(np.uint32)
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(S.ACCEL_TWO_LEVEL)
+        c.upload_scene(sc); c.resize(96, 64)
+        assert c.build_info().structure == S.ACCEL_TWO_LEVEL
+        c.render(cb, accum_count=2, flags=S.FRAME_WAVEFRONT); wf = c.read_accumulation()
+        c.resize(96, 64)
+        c.render(cb, accum_count=1, flags=S.FRAME_MEGAKERNEL)
+        c.render(scenes.fill_constants(view, pos, sc, 1, 5), accum_count=1, flags=S.FRAME_MEGAKERNEL); mk = c.read_accumulation()
+        assert np.array_equal(wf.view(np.uint32), mk.view(np.uint32)) and wf[..., :3].max() > 0
+        for shadow in (False, True):
+            a, b = c.trace_rays(rays, shadow=shadow), c.trace_rays(rays, shadow=shadow, thread_per_ray=True)
+            assert a.tobytes() == b.tobytes() and (a["hit"] > 0).mean() > 0.05
+        with pytest.raises(HrptError):
+            c.selftest_bvh()
+    finally:
+        c.close()
+
+
+def test_two_level_material_change_keeps_the_structure(luts):
+    from hobbyrenderer_amd.native import PathTracerContext
     n = 4
     sc = instanced_scene(luts, n)
     view, pos = _camera(64, 64, n)
@@ -345,15 +380,6 @@ def test_entry_points_that_do_not_traverse_the_two_level_structure_refuse(luts):
         c.set_acceleration_structure(S.ACCEL_TWO_LEVEL)
         c.upload_scene(sc)
         c.resize(64, 64)
-        with pytest.raises(HrptError):
-            c.render(scenes.fill_constants(view, pos, sc, 0, 2), accum_count=1, flags=S.FRAME_MEGAKERNEL)
-        with pytest.raises(HrptError):
-            c.selftest_bvh()
-        rays = np.zeros(4, S.Ray)
-        rays["direction"] = (0, 0, 1)
-        rays["tmax"] = 10
-        with pytest.raises(HrptError):
-            c.trace_rays(rays, thread_per_ray=True)         # the persistent kernel does (test_ray_queries_over_the_two_level_structure)
         # a material change that makes an instance non-opaque rebuilds the structure (instance flags), still two-level
         m = sc.materials.copy()
         m["m_AlphaMode"][1] = S.ALPHA_MODE_BLEND
