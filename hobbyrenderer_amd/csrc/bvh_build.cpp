@@ -235,6 +235,18 @@ void collapse_bvh2_on_host(const std::vector<HostNode>& nodes2, std::vector<Host
     collapse4(nodes2, 0, nodes4, 0, maxDepth4);
 }
 
+// The largest side of a triangle's bounding box. The watertight test computes t from vertex coordinates relative to the ray origin: for a hit
+// next to the origin (t ~ tmin) its rounding error is a few ulp of the triangle's SIZE, whatever the size of t -- measured: a 460-unit floor
+// quad reports t = 1.01e-4 for a true 0.89e-4. A box padded by its own coordinates alone (1e-6 around a floor at y = 0) is then tighter than
+// the test it guards, and which hits survive starts to depend on the boxes (fp32 against quantised nodes: 53 of 2.5 M surface-leaving rays).
+// Hence 1e-6 (8 ulp) of this on every side, on top of the coordinate term.
+static inline float triangle_extent(const HostTri& t)
+{
+    float e = 0.0f;
+    for (int k = 0; k < 3; ++k) e = std::max(e, std::max(t.p0[k], std::max(t.p1[k], t.p2[k])) - std::min(t.p0[k], std::min(t.p1[k], t.p2[k])));
+    return e;
+}
+
 bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& error, bool flatLimit)
 {
     triCount = 0;
@@ -305,11 +317,12 @@ bool build_scene_bvh(const HrptSceneDesc& s, BuiltBvh& out, std::string& error)
     b.prims.resize(tris.size());
     for (size_t i = 0; i < tris.size(); ++i) {
         Prim& p = b.prims[i]; const HostTri& t = tris[i];
+        const float extPad = 1e-6f * triangle_extent(t);
         for (int k = 0; k < 3; ++k) {
             float mn = std::min(t.p0[k], std::min(t.p1[k], t.p2[k])), mx = std::max(t.p0[k], std::max(t.p1[k], t.p2[k]));
             if (!(mn == mn) || !(mx == mx) || std::isinf(mn) || std::isinf(mx)) { error = "non-finite vertex position"; return false; }
-            // conservative padding: the fp32 watertight test can accept points a few ulp outside the triangle
-            float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f;
+            // conservative padding: the fp32 watertight test can accept points a few ulp outside the triangle (see triangle_extent)
+            float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f + extPad;
             p.bmin[k] = mn - pad; p.bmax[k] = mx + pad; p.c[k] = 0.5f * mn + 0.5f * mx;
         }
         p.tri = (uint32_t)i;
@@ -392,10 +405,11 @@ bool build_mesh_trees(const HrptSceneDesc& s, BuiltTwoLevel& out, std::vector<in
         b.prims.resize(nt);
         for (uint32_t p = 0; p < nt; ++p) {
             Prim& pr = b.prims[p]; const HostTri& t = tris[p];
+            const float extPad = 1e-6f * triangle_extent(t);
             for (int k = 0; k < 3; ++k) {
                 float mn = std::min(t.p0[k], std::min(t.p1[k], t.p2[k])), mx = std::max(t.p0[k], std::max(t.p1[k], t.p2[k]));
                 if (!(mn == mn) || !(mx == mx) || std::isinf(mn) || std::isinf(mx)) { error = "non-finite vertex position"; return false; }
-                float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f;
+                float pad = 1e-5f * std::max(std::fabs(mn), std::fabs(mx)) + 1e-6f + extPad;
                 pr.bmin[k] = mn - pad; pr.bmax[k] = mx + pad; pr.c[k] = 0.5f * mn + 0.5f * mx;
             }
             pr.tri = p;
@@ -437,7 +451,7 @@ bool build_mesh_trees(const HrptSceneDesc& s, BuiltTwoLevel& out, std::vector<in
 }
 }
 
-bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error)
+bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error, std::vector<float>* worldBoxes)
 {
     // mesh roots are recovered from the existing instance records (same mesh -> same root)
     std::vector<int32_t> meshRoot(s.meshDataCount, 0); std::vector<uint8_t> have(s.meshDataCount, 0);
@@ -468,9 +482,10 @@ bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std
                 for (int k = 0; k < 3; ++k) if (!std::isfinite(w[k])) { error = "non-finite vertex position"; return false; }
                 wb.grow(w, w);
             }
+            const float extPad = 1e-6f * std::max(wb.mx[0] - wb.mn[0], std::max(wb.mx[1] - wb.mn[1], wb.mx[2] - wb.mn[2]));      // as for triangles (triangle_extent): no triangle inside is larger
             for (int k = 0; k < 3; ++k) {
                 maxAbs = std::max(maxAbs, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])));
-                const float pad = 1e-5f * std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + 1e-6f;
+                const float pad = 1e-5f * std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + 1e-6f + extPad;
                 wb.mn[k] -= pad; wb.mx[k] += pad;
             }
         } else { for (int k = 0; k < 3; ++k) { wb.mn[k] = wb.mx[k] = M[12 + k]; } }
@@ -493,6 +508,13 @@ bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std
     build_instance_shade(s, out.instShade);
     // the tree over the instances replaces the first tlasNodeCount nodes: rebuild the array with the mesh trees shifted if its size changes
     std::vector<HostNode4> tlas; uint32_t dT = 0; int32_t rootLeaf = 0;
+    if (worldBoxes) {           // tree built by the caller (GPU): reserve the node range, hand out the boxes
+        worldBoxes->resize((size_t)s.instanceCount * 6);
+        for (uint32_t i = 0; i < s.instanceCount; ++i) for (int k = 0; k < 3; ++k) { (*worldBoxes)[(size_t)i * 6 + k] = b.prims[i].bmin[k]; (*worldBoxes)[(size_t)i * 6 + 3 + k] = b.prims[i].bmax[k]; }
+        HostNode4 empty{};
+        for (int k = 0; k < 4; ++k) { empty.child[k] = kEmptyChild; empty.minx[k] = empty.miny[k] = empty.minz[k] = empty.maxx[k] = empty.maxy[k] = empty.maxz[k] = 1e30f; }
+        tlas.assign(s.instanceCount, empty);
+    } else
     if (s.instanceCount > 0) {
         Box root;
         const int32_t r = b.build(0, s.instanceCount, 0, root);
@@ -515,7 +537,7 @@ bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std
     return true;
 }
 
-bool build_scene_two_level(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error)
+bool build_scene_two_level(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error, std::vector<float>* worldBoxes)
 {
     out = BuiltTwoLevel();
     uint64_t triCount = 0;
@@ -526,7 +548,7 @@ bool build_scene_two_level(const HrptSceneDesc& s, BuiltTwoLevel& out, std::stri
     // seed instance records so that rebuild_two_level_instances finds the mesh roots
     out.instances.assign(s.instanceCount, HostInstance{});
     for (uint32_t i = 0; i < s.instanceCount; ++i) { out.instances[i].mesh = s.instances[i].m_MeshDataIndex; out.instances[i].blasRoot = meshRoot[s.instances[i].m_MeshDataIndex]; }
-    return rebuild_two_level_instances(s, out, error);
+    return rebuild_two_level_instances(s, out, error, worldBoxes);
 }
 
 } // namespace hrt

@@ -117,10 +117,13 @@ struct BuiltTwoLevel {
 };
 // Stack need of the two-level traversal: 3 entries per 4-wide level of both trees + the BLAS exit marker + 2.
 inline uint32_t two_level_stack_need(const BuiltTwoLevel& b) { return 3u * (b.maxDepth4Tlas + b.maxDepth4Blas) + 3u; }
-bool build_scene_two_level(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error);
+bool build_scene_two_level(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error, std::vector<float>* worldBoxes = nullptr);
 // The instance records + the tree over the instances only (moving objects: the per-frame TLAS rebuild of src/CommonRenderers.cpp:234-246);
 // `out` keeps its mesh trees.
-bool rebuild_two_level_instances(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error);
+// worldBoxes != nullptr: the tree is NOT built -- the caller builds it on the GPU from the padded world boxes returned here (6 floats per
+// instance: min xyz, max xyz) and writes it into the first scene.instanceCount nodes, which this call reserves (tlasNodeCount = instanceCount,
+// the mesh trees behind them; maxDepth4Tlas is the caller's to set).
+bool rebuild_two_level_instances(const HrptSceneDesc& scene, BuiltTwoLevel& out, std::string& error, std::vector<float>* worldBoxes = nullptr);
 
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr uint32_t kTraversalStackDepth = 64;   // 2-wide trees: the builders guarantee depth + 2 <= this (private / LDS + overflow stacks of the kernels)

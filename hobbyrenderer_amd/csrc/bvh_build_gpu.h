@@ -19,6 +19,7 @@ struct GpuBuiltBvh {            // device pointers owned by the GpuBvhBuilder th
     uint32_t mortonBits = 0;    // Morton bits the hierarchy used (63, or fewer when the full-code tree was too deep)
     float sahCost = 0.0f;       // surface-area-heuristic cost of the 2-wide tree (node cost 1, triangle cost 1), root area = 1
     float deviceMs = 0.0f;      // instance upload .. last kernel
+    const uint32_t* leafOrder = nullptr;   // primitive (input index) at every position of the leaf order the leaf references count in
 };
 
 // Keeps the scene's geometry (quantised vertices, indices) and every build buffer on the device, so that a rebuild after a transform
@@ -37,9 +38,18 @@ public:
     // with fewer Morton bits until maxDepth + 2 <= maxStackDepth (the caller still checks the final depth). Synchronises `stream`.
     hipError_t build(const HrptPerInstanceData* instances, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
     size_t deviceBytes() const;
+    // Box mode -- the tree over the instances of the two-level structure (pt_capi.cpp build_two_level): `count` boxes (6 floats each, min xyz
+    // then max xyz, taken as they are), one per leaf, Morton grid over the cube of the largest extent. The result has nodes / nodes4 /
+    // leafOrder only; a leaf reference ~(k << 2) names box leafOrder[k].
+    hipError_t prepare_boxes(uint32_t count, hipStream_t stream, std::string& error);
+    hipError_t build_boxes(const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
 private:
+    hipError_t allocate(uint32_t n, const HrptSceneDesc* scene, bool needTangents, hipStream_t stream, std::string& error);
+    hipError_t build_any(const HrptPerInstanceData* instances, const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
     struct Impl;
     Impl* p = nullptr;
 };
+// copies the `count` 4-wide nodes of a tree built in box mode to `dst`, leaves rewritten as two-level instance references ~(instance << 2)
+hipError_t launch_tlas_fixup(const GpuNode4* src, uint32_t count, const uint32_t* leafOrder, GpuNode4* dst, hipStream_t stream);
 
 } // namespace hrt

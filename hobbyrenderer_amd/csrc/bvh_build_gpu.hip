@@ -35,6 +35,8 @@ struct InstRec {            // per instance, host-prepared
 struct BuildBuffers {
     // inputs
     const HrptVertexQuantized* vertices; const uint32_t* indices; const InstRec* inst; uint32_t instCount; uint32_t triCount;
+    const float* boxesIn;       // box mode (prepare_boxes): 6 floats per primitive, min xyz then max xyz; no triangles, no attribute records
+    uint32_t cubeMorton;        // Morton grid over the cube of the largest centroid extent instead of the per-axis box (trees over instances: flat layouts)
     // per unsorted triangle
     GpuTri* triU; float4* boxMinU; float4* boxMaxU;
     uint64_t* keyA; uint64_t* keyB; uint32_t* valA; uint32_t* valB;
@@ -74,6 +76,22 @@ __device__ __forceinline__ uint32_t find_instance(const InstRec* inst, uint32_t 
     return lo;
 }
 
+// block reduction of the centroid bounds, one atomic pair per axis per block
+__device__ __forceinline__ void reduce_centroid_bounds(const BuildBuffers& b, const float (&cmin)[3], const float (&cmax)[3])
+{
+    __shared__ float smin[3][kB / 64], smax[3][kB / 64];
+    for (int k = 0; k < 3; ++k) {
+        float lo = cmin[k], hi = cmax[k];
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+        if ((threadIdx.x & 63) == 0) { smin[k][threadIdx.x >> 6] = lo; smax[k][threadIdx.x >> 6] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float lo = smin[threadIdx.x][0], hi = smax[threadIdx.x][0];
+        for (int w = 1; w < kB / 64; ++w) { lo = fminf(lo, smin[threadIdx.x][w]); hi = fmaxf(hi, smax[threadIdx.x][w]); }
+        if (lo <= hi) { atomicMin(&b.sceneBounds[threadIdx.x], ordered(lo)); atomicMax(&b.sceneBounds[3 + threadIdx.x], ordered(hi)); }
+    }
+}
 // ---- 1. world-space triangles, padded boxes, centroid bounds
 __global__ __launch_bounds__(kB) void k_setup(BuildBuffers b)
 {
@@ -91,10 +109,13 @@ __global__ __launch_bounds__(kB) void k_setup(BuildBuffers b)
         t.inst = i; t.prim = p; t.flags = in.opaque;
         b.triU[g] = t;
         float mn[3], mx[3], c[3]; bool bad = false;
+        float ext = 0.0f;
+        for (int k = 0; k < 3; ++k) ext = fmaxf(ext, fmaxf(v[0][k], fmaxf(v[1][k], v[2][k])) - fminf(v[0][k], fminf(v[1][k], v[2][k])));
+        const float extPad = 1e-6f * ext;                                 // bvh_build.cpp triangle_extent
         for (int k = 0; k < 3; ++k) {
             float lo = fminf(v[0][k], fminf(v[1][k], v[2][k])), hi = fmaxf(v[0][k], fmaxf(v[1][k], v[2][k]));
             bad = bad || !(v[0][k] == v[0][k]) || !(v[1][k] == v[1][k]) || !(v[2][k] == v[2][k]) || isinf(lo) || isinf(hi);
-            float pad = 1e-5f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;      // the host builder's conservative padding
+            float pad = 1e-5f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f + extPad;      // the host builder's conservative padding
             mn[k] = lo - pad; mx[k] = hi + pad; c[k] = 0.5f * lo + 0.5f * hi;
             cmin[k] = c[k]; cmax[k] = c[k];
         }
@@ -103,19 +124,29 @@ __global__ __launch_bounds__(kB) void k_setup(BuildBuffers b)
         b.boxMaxU[g] = make_float4(mx[0], mx[1], mx[2], c[1]);
         b.keyA[g] = (uint64_t)__float_as_uint(c[2]);          // parked: centroid z until k_morton replaces it
     }
-    // block reduction of the centroid bounds, one atomic pair per axis per block
-    __shared__ float smin[3][kB / 64], smax[3][kB / 64];
-    for (int k = 0; k < 3; ++k) {
-        float lo = cmin[k], hi = cmax[k];
-        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
-        if ((threadIdx.x & 63) == 0) { smin[k][threadIdx.x >> 6] = lo; smax[k][threadIdx.x >> 6] = hi; }
+    reduce_centroid_bounds(b, cmin, cmax);
+}
+// ---- 1'. box mode: the primitives are boxes already (the instances of the two-level structure, padded by the host: bvh_build.cpp
+// rebuild_two_level_instances), taken as they are
+__global__ __launch_bounds__(kB) void k_setup_boxes(BuildBuffers b)
+{
+    uint32_t g = blockIdx.x * kB + threadIdx.x;
+    float cmin[3] = { 3e38f, 3e38f, 3e38f }, cmax[3] = { -3e38f, -3e38f, -3e38f };
+    if (g < b.triCount) {
+        const float* in = b.boxesIn + 6 * (size_t)g;
+        float mn[3], mx[3], c[3]; bool bad = false;
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = in[k]; mx[k] = in[3 + k];
+            bad = bad || !(mn[k] <= mx[k]) || isinf(mn[k]) || isinf(mx[k]);
+            c[k] = 0.5f * mn[k] + 0.5f * mx[k];
+            cmin[k] = c[k]; cmax[k] = c[k];
+        }
+        if (bad) atomicOr(&b.flags[0], 1u);
+        b.boxMinU[g] = make_float4(mn[0], mn[1], mn[2], c[0]);
+        b.boxMaxU[g] = make_float4(mx[0], mx[1], mx[2], c[1]);
+        b.keyA[g] = (uint64_t)__float_as_uint(c[2]);
     }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        float lo = smin[threadIdx.x][0], hi = smax[threadIdx.x][0];
-        for (int w = 1; w < kB / 64; ++w) { lo = fminf(lo, smin[threadIdx.x][w]); hi = fmaxf(hi, smax[threadIdx.x][w]); }
-        if (lo <= hi) { atomicMin(&b.sceneBounds[threadIdx.x], ordered(lo)); atomicMax(&b.sceneBounds[3 + threadIdx.x], ordered(hi)); }
-    }
+    reduce_centroid_bounds(b, cmin, cmax);
 }
 
 __device__ __forceinline__ uint64_t spread21(uint32_t x)
@@ -136,9 +167,13 @@ __global__ __launch_bounds__(kB) void k_morton(BuildBuffers b)
     if (g >= b.triCount) return;
     float c[3] = { b.boxMinU[g].w, b.boxMaxU[g].w, __uint_as_float((uint32_t)b.keyA[g]) };
     uint32_t q[3];
+    // instances usually stand on a ground plane: a per-axis grid would spend every third bit on their small height differences and tear
+    // horizontal neighbours apart in the order; one cell size for all axes keeps the order 2-D until the cells are as small as the heights
+    float cube = 0.0f;
+    for (int k = 0; k < 3; ++k) cube = fmaxf(cube, unordered(b.sceneBounds[3 + k]) - unordered(b.sceneBounds[k]));
     for (int k = 0; k < 3; ++k) {
         float lo = unordered(b.sceneBounds[k]), hi = unordered(b.sceneBounds[3 + k]);
-        float ext = hi - lo;
+        float ext = b.cubeMorton ? cube : hi - lo;
         float t = ext > 0.0f ? (c[k] - lo) / ext : 0.0f;
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         uint32_t v = (uint32_t)(t * 2097151.0f);
@@ -245,14 +280,14 @@ __global__ __launch_bounds__(kB) void k_ploc_init(BuildBuffers b)
 }
 // The iteration state lives on the device (plocState: [0] clusters left, [1] nodes created, [2] error), so that a batch of iterations runs
 // without a host round trip; grids and scan lengths use the cluster count of the batch's start (an upper bound inside the batch).
-__global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* __restrict__ cluster)
+__global__ __launch_bounds__(kB) void k_ploc_nn(BuildBuffers b, const uint32_t* __restrict__ cluster, int radius)
 {
     const uint32_t count = b.plocState[0];
     uint32_t i = blockIdx.x * kB + threadIdx.x;
     if (i >= count) return;
     uint32_t me = cluster[i];
     float4 mn = b.pMin[me], mx = b.pMax[me];
-    int lo = (int)i - kPlocRadius < 0 ? 0 : (int)i - kPlocRadius, hi = (int)i + kPlocRadius >= (int)count ? (int)count - 1 : (int)i + kPlocRadius;
+    int lo = (int)i - radius < 0 ? 0 : (int)i - radius, hi = (int)i + radius >= (int)count ? (int)count - 1 : (int)i + radius;
     float best = 3e38f; uint32_t bestJ = i;
     for (int j = lo; j <= hi; ++j) {
         if (j == (int)i) continue;
@@ -547,6 +582,8 @@ struct GpuBvhBuilder::Impl {
     std::vector<InstRec> inst;         // static part filled at prepare(), world matrices per build()
     size_t sortBytes = 0, scanBytes = 0, bytes = 0;
     uint32_t n = 0;
+    bool boxes = false;                // prepare_boxes(): the primitives are boxes (one per leaf), no triangle / attribute outputs
+    uint32_t maxLeaf = 0;              // 0: the default leaf size (2, HRPT_GPU_BVH_MAX_LEAF); 1 in box mode
     int lastBudget = -1; bool lastUsePloc = false;   // hierarchy attempt that fitted the stacks at the previous build(): a rebuild starts there
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~Impl()
@@ -567,7 +604,6 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
 {
     delete p; p = new Impl();
     Impl& m = *p;
-    hipError_t e;
     // instance table + triangle prefix (host, O(instances)); mesh / material / opacity of an instance never change between rebuilds
     m.inst.resize(s.instanceCount);
     uint64_t T = 0;
@@ -579,7 +615,23 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
         T += md.m_IndexCounts[0] / 3;
     }
     if (T < 8 || T >= (1ull << 29)) { error = "triangle count outside the GPU builder's range"; return hipErrorInvalidValue; }
-    const uint32_t n = m.n = (uint32_t)T;
+    return allocate((uint32_t)T, &s, needTangents, stream, error);
+}
+
+hipError_t GpuBvhBuilder::prepare_boxes(uint32_t count, hipStream_t stream, std::string& error)
+{
+    delete p; p = new Impl();
+    p->boxes = true; p->maxLeaf = 1;
+    if (count < 8 || count >= (1u << 25)) { error = "box count outside the GPU builder's range"; return hipErrorInvalidValue; }
+    return allocate(count, nullptr, false, stream, error);
+}
+
+// every device buffer of a build over n primitives; `s` (triangle mode) also brings the geometry to the device
+hipError_t GpuBvhBuilder::allocate(uint32_t n, const HrptSceneDesc* s, bool needTangents, hipStream_t stream, std::string& error)
+{
+    Impl& m = *p;
+    hipError_t e;
+    m.n = n;
     if (hipEventCreate(&m.ev0) != hipSuccess || hipEventCreate(&m.ev1) != hipSuccess) { error = "hipEventCreate"; return hipErrorUnknown; }
 
     // rocPRIM scratch sizes
@@ -590,7 +642,7 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
     Arena A;
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 sizes the arena, pass 1 hands out pointers
         A.off = 0;
-        b.triU = A.take<GpuTri>(n); b.boxMinU = A.take<float4>(n); b.boxMaxU = A.take<float4>(n);
+        b.triU = A.take<GpuTri>(m.boxes ? 0 : n); b.boxMinU = A.take<float4>(n); b.boxMaxU = A.take<float4>(n);
         b.keyA = A.take<uint64_t>(n); b.keyB = A.take<uint64_t>(n); b.valA = A.take<uint32_t>(n); b.valB = A.take<uint32_t>(n);
         b.sceneBounds = A.take<uint32_t>(8); b.flags = A.take<uint32_t>(8); b.plocState = A.take<uint32_t>(8);
         b.childL = A.take<uint32_t>(n); b.childR = A.take<uint32_t>(n); b.rangeFirst = A.take<uint32_t>(n); b.rangeLast = A.take<uint32_t>(n);
@@ -604,46 +656,67 @@ hipError_t GpuBvhBuilder::prepare(const HrptSceneDesc& s, bool needTangents, hip
         b.clusterA = A.take<uint32_t>(n); b.clusterB = A.take<uint32_t>(n); b.nn = A.take<uint32_t>(n); b.mergeFlag = A.take<uint32_t>(n); b.validFlag = A.take<uint32_t>(n);
         b.mergeIdx = A.take<uint32_t>(n); b.validIdx = A.take<uint32_t>(n);
         b.nodes = A.take<GpuNode>(n);            // the traversal kernels read the trees in place: a rebuild may change the node counts
-        b.nodes4 = A.take<GpuNode4>(n / 2 + 1);
+        b.nodes4 = A.take<GpuNode4>(m.maxLeaf == 1 ? n : n / 2 + 1);      // (single-primitive leaves: up to n - 1 inner nodes survive the collapse of a degenerate tree)
         m.prim = A.take<char>(std::max(m.sortBytes, m.scanBytes));
-        char* vtx = A.take<char>((size_t)s.vertexCount * sizeof(HrptVertexQuantized));
-        char* idx = A.take<char>((size_t)s.indexCount * 4);
+        char* vtx = A.take<char>(s ? (size_t)s->vertexCount * sizeof(HrptVertexQuantized) : 0);
+        char* idx = A.take<char>(s ? (size_t)s->indexCount * 4 : 0);
         char* ins = A.take<char>(m.inst.size() * sizeof(InstRec));
+        b.boxesIn = A.take<float>(m.boxes ? 6 * (size_t)n : 0);
         b.vertices = reinterpret_cast<const HrptVertexQuantized*>(vtx); b.indices = reinterpret_cast<const uint32_t*>(idx); b.inst = reinterpret_cast<const InstRec*>(ins);
         if (pass == 0) {
             if ((e = hipMalloc(&m.scratch, A.off)) != hipSuccess) { error = "hipMalloc(GPU BVH build arena)"; return e; }
             A.base = static_cast<char*>(m.scratch); A.cap = A.off;
         }
     }
-    m.bytes = A.cap + (size_t)n * (sizeof(GpuTri) + sizeof(GpuTriAttr) + (needTangents ? sizeof(GpuTriTangent) : 0));
-    b.instCount = s.instanceCount; b.triCount = n;
+    b.instCount = (uint32_t)m.inst.size(); b.triCount = n; b.cubeMorton = m.boxes ? 1u : 0u;
+    if (const char* e = getenv("HRPT_GPU_BVH_CUBE_MORTON")) b.cubeMorton = atoi(e) != 0;
+    b.tris = nullptr; b.attrs = nullptr; b.tangents = nullptr;
+    m.bytes = A.cap;
+    if (m.boxes) return hipSuccess;
+    m.bytes += (size_t)n * (sizeof(GpuTri) + sizeof(GpuTriAttr) + (needTangents ? sizeof(GpuTriTangent) : 0));
     if ((e = hipMalloc((void**)&m.tris, (size_t)n * sizeof(GpuTri))) != hipSuccess || (e = hipMalloc((void**)&m.attrs, (size_t)n * sizeof(GpuTriAttr))) != hipSuccess ||
         (needTangents && (e = hipMalloc((void**)&m.tangents, (size_t)n * sizeof(GpuTriTangent))) != hipSuccess)) { error = "hipMalloc(GPU BVH outputs)"; return hipErrorOutOfMemory; }
     b.tris = m.tris; b.attrs = m.attrs; b.tangents = m.tangents;
-    if ((e = hipMemcpyAsync(const_cast<HrptVertexQuantized*>(b.vertices), s.vertices, (size_t)s.vertexCount * sizeof(HrptVertexQuantized), hipMemcpyHostToDevice, stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(const_cast<uint32_t*>(b.indices), s.indices, (size_t)s.indexCount * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+    if ((e = hipMemcpyAsync(const_cast<HrptVertexQuantized*>(b.vertices), s->vertices, (size_t)s->vertexCount * sizeof(HrptVertexQuantized), hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(const_cast<uint32_t*>(b.indices), s->indices, (size_t)s->indexCount * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
         (e = hipStreamSynchronize(stream)) != hipSuccess) { error = "hipMemcpyAsync(GPU BVH inputs)"; return e; }
     return hipSuccess;
 }
 
+hipError_t GpuBvhBuilder::build_boxes(const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    if (!p || !p->boxes) { error = "GPU BVH builder not prepared for boxes"; return hipErrorInvalidValue; }
+    return build_any(nullptr, boxes, usePloc, maxStackDepth, stream, out, error);
+}
 hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
 {
+    if (!p || p->boxes) { error = "GPU BVH builder not prepared"; return hipErrorInvalidValue; }
+    return build_any(instances, nullptr, usePloc, maxStackDepth, stream, out, error);
+}
+
+hipError_t GpuBvhBuilder::build_any(const HrptPerInstanceData* instances, const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
     out = GpuBuiltBvh();
-    if (!p || !p->scratch) { error = "GPU BVH builder not prepared"; return hipErrorInvalidValue; }
+    if (!p->scratch) { error = "GPU BVH builder not prepared"; return hipErrorInvalidValue; }
     Impl& m = *p;
     hipError_t e;
     BuildBuffers b = m.b0;
     const uint32_t n = m.n;
     void* const prim = m.prim; size_t sortBytes = m.sortBytes, scanBytes = m.scanBytes;   // rocPRIM takes the size by non-const reference
-    for (size_t i = 0; i < m.inst.size(); ++i) std::memcpy(m.inst[i].world, instances[i].m_World, sizeof m.inst[i].world);
     auto fail = [&](hipError_t err, const char* what) { error = what; (void)hipStreamSynchronize(stream); return err; };
-    if ((e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), m.inst.data(), m.inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
-        return fail(e, "hipMemcpyAsync(GPU BVH instances)");
+    if (m.boxes) {
+        if ((e = hipMemcpyAsync(const_cast<float*>(b.boxesIn), boxes, (size_t)n * 24, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e, "hipMemcpyAsync(GPU BVH boxes)");
+    } else {
+        for (size_t i = 0; i < m.inst.size(); ++i) std::memcpy(m.inst[i].world, instances[i].m_World, sizeof m.inst[i].world);
+        if ((e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), m.inst.data(), m.inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync(GPU BVH instances)");
+    }
     hipEvent_t ev0 = m.ev0, ev1 = m.ev1;
     (void)hipEventRecord(ev0, stream);
     const dim3 gT((n + kB - 1) / kB), blk(kB);
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, b.sceneBounds, b.flags);
-    hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
+    if (m.boxes) hipLaunchKernelGGL(k_setup_boxes, gT, blk, 0, stream, b);
+    else hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
     hipLaunchKernelGGL(k_morton, gT, blk, 0, stream, b);
     if ((e = rocprim::radix_sort_pairs(prim, sortBytes, b.keyA, b.keyB, b.valA, b.valB, n, 0, 63, stream)) != hipSuccess) return fail(e, "rocprim::radix_sort_pairs");
     // Hierarchy attempts, best tree first: PLOC (when asked for), then the radix tree over the full 63-bit codes, then radix trees over
@@ -651,6 +724,9 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     uint32_t nodeCount = 0, maxDepthSeen = 0; int usedBits = 0; bool usedPloc = false;
     uint32_t maxLeafTris = 2;          // measured with the greedy collapse: 2 beats 4 on all three test scenes for both hierarchies (-2..-6 % frame time)
     if (const char* e = getenv("HRPT_GPU_BVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) maxLeafTris = (uint32_t)v; }
+    if (m.maxLeaf >= 1 && m.maxLeaf <= 4) maxLeafTris = m.maxLeaf;
+    int plocRadius = kPlocRadius;
+    if (const char* e = getenv("HRPT_GPU_PLOC_RADIUS")) { int v = atoi(e); if (v >= 1 && v <= 256) plocRadius = v; }
     const int attempts[] = { 64, 63, 48, 39, 30, 21, 12, 0 };          // 64 = PLOC
     uint32_t* const mortonOrder = b.valB;                              // leaf k of the radix tree = triangle mortonOrder[k]
     if (m.lastUsePloc != usePloc) m.lastBudget = -1;
@@ -668,7 +744,7 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
                 const uint32_t bound = count;                          // no cluster list of this batch is longer
                 const dim3 gC((bound + kB - 1) / kB);
                 for (int it = 0; it < 6; ++it) {
-                    hipLaunchKernelGGL(k_ploc_nn, gC, blk, 0, stream, b, cur);
+                    hipLaunchKernelGGL(k_ploc_nn, gC, blk, 0, stream, b, cur, plocRadius);
                     hipLaunchKernelGGL(k_ploc_flags, gC, blk, 0, stream, b, bound);
                     if ((e = rocprim::exclusive_scan(prim, scanBytes, b.mergeFlag, b.mergeIdx, 0u, bound, rocprim::plus<uint32_t>(), stream)) != hipSuccess ||
                         (e = rocprim::exclusive_scan(prim, scanBytes, b.validFlag, b.validIdx, 0u, bound, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(PLOC)");
@@ -727,7 +803,7 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     float* sahDev = reinterpret_cast<float*>(b.flags + 4);
     (void)hipMemsetAsync(sahDev, 0, 4, stream);
     hipLaunchKernelGGL(k_sah, gN, blk, 0, stream, b, nodeCount, sahDev);
-    hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
+    if (!m.boxes) hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
     (void)hipEventRecord(ev1, stream);
     uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 }; float sahSum = 0.0f; GpuNode rootNode;
     if ((e = hipMemcpyAsync(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
@@ -740,7 +816,7 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     const uint32_t node4Count = tail4[0] + tail4[1];
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev0, ev1);
     out.nodes = b.nodes; out.nodeCount = nodeCount; out.nodes4 = b.nodes4; out.node4Count = node4Count;
-    out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n;
+    out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n; out.leafOrder = b.valB;
     {   // root box = union of the root's two child boxes
         float dx = std::max(rootNode.lmax[0], rootNode.rmax[0]) - std::min(rootNode.lmin[0], rootNode.rmin[0]);
         float dy = std::max(rootNode.lmax[1], rootNode.rmax[1]) - std::min(rootNode.lmin[1], rootNode.rmin[1]);
@@ -750,6 +826,28 @@ hipError_t GpuBvhBuilder::build(const HrptPerInstanceData* instances, bool usePl
     }
     out.maxDepth = maxDepthSeen; out.maxDepth4 = flags[2]; out.mortonBits = (uint32_t)usedBits; out.ploc = usedPloc; out.deviceMs = ms;
     return hipSuccess;
+}
+
+// ---- the tree over the INSTANCES of the two-level structure (box mode): copies the nodes to the front of the scene's node array with every
+// leaf -- position k of the final leaf order -- turned into the instance reference the two-level traversal expects, ~(instance << 2)
+__global__ __launch_bounds__(256) void k_tlas_fixup(const GpuNode4* __restrict__ src, uint32_t count, const uint32_t* __restrict__ leafOrder, GpuNode4* __restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    GpuNode4 n = src[i];
+    int32_t* ch = &n.child.x;
+    for (int c = 0; c < 4; ++c) {
+        if (ch[c] == 0x7fffffff || ch[c] >= 0) continue;
+        const uint32_t first = ((uint32_t)~ch[c]) >> 2;
+        ch[c] = ~(int32_t)(leafOrder[first] << 2);
+    }
+    dst[i] = n;
+}
+hipError_t launch_tlas_fixup(const GpuNode4* src, uint32_t count, const uint32_t* leafOrder, GpuNode4* dst, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tlas_fixup, dim3((count + 255) / 256), dim3(256), 0, stream, src, count, leafOrder, dst);
+    return hipGetLastError();
 }
 
 } // namespace hrt

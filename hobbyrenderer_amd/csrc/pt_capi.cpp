@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <stdexcept>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,7 @@ struct HrptContext {
     std::vector<void*> bvhAllocations;       // acceleration structure of the host builder + per-instance records: replaced by hrpt_update_instances
     GpuNodeQ* nodesQ = nullptr; size_t nodesQCapacity = 0;    // quantised copy of the flat 4-wide tree (pt_device.h GpuNodeQ), kept across rebuilds
     GpuBvhBuilder* gpuBuilder = nullptr;     // GPU builders: geometry + build buffers stay on the device for rebuilds
+    GpuBvhBuilder* tlasBuilder = nullptr; uint32_t tlasBuilderInstances = 0;   // two-level structure: the tree over the instances, built on the GPU (build_two_level)
     // host copy of what a rebuild needs (the reference's Scene keeps the same vectors: m_InstanceData, m_Vertices, m_Indices, m_MeshData)
     std::vector<HrptVertexQuantized> keptVertices; std::vector<uint32_t> keptIndices; std::vector<HrptMeshData> keptMeshData;
     std::vector<HrptPerInstanceData> keptInstances; std::vector<HrptMaterialConstants> keptMaterials; std::vector<HrptGPULight> keptLights;
@@ -97,6 +99,7 @@ static void free_acceleration(HrptContext* c, bool keepGpuBuilder)
     c->bvhAllocations.clear();
     if (!keepGpuBuilder) {
         delete c->gpuBuilder; c->gpuBuilder = nullptr;
+        delete c->tlasBuilder; c->tlasBuilder = nullptr; c->tlasBuilderInstances = 0;
         for (void* p : c->meshAllocations) (void)hipFree(p);
         c->meshAllocations.clear();
         delete c->twoLevel; c->twoLevel = nullptr;
@@ -219,20 +222,46 @@ static bool two_level_wanted(const HrptContext* c, const HrptSceneDesc& s, uint6
 // kTwoLevelDoesNotFit: the scene cannot be held in this form (an instance with a singular world matrix -- a mesh flattened to a plane --, trees
 // too deep): the caller builds the flat structure instead, which has no such limits
 constexpr int kTwoLevelDoesNotFit = 1;
+// The tree over the instances on the GPU (the reference rebuilds its TLAS on the GPU every frame, src/CommonRenderers.cpp:234-246): the
+// builder's box mode over the instances' padded world boxes, then launch_tlas_fixup writes the nodes, leaves turned into instance references,
+// to the front of the scene's node array. The builder and its buffers stay on the device: a rebuild (hrpt_update_instances) uploads 24 bytes
+// per instance and runs the kernels. false: not built (a device error, a tree too deep): the caller builds the tree on the host instead.
+static bool build_instance_tree_on_gpu(HrptContext* c, uint32_t instanceCount, const std::vector<float>& boxes, GpuNode4* dstNodes, uint32_t& depth4Levels)
+{
+    std::string gerr;
+    if (!c->tlasBuilder || c->tlasBuilderInstances != instanceCount) {
+        delete c->tlasBuilder; c->tlasBuilder = new GpuBvhBuilder(); c->tlasBuilderInstances = 0;
+        if (c->tlasBuilder->prepare_boxes(instanceCount, c->stream, gerr) != hipSuccess) { delete c->tlasBuilder; c->tlasBuilder = nullptr; return false; }
+        c->tlasBuilderInstances = instanceCount;
+    }
+    GpuBuiltBvh g;
+    const bool ploc = !getenv("HRPT_TLAS_LBVH");
+    if (c->tlasBuilder->build_boxes(boxes.data(), ploc, kTraversalStackDepth, c->stream, g, gerr) != hipSuccess || g.maxDepth + 2 > kTraversalStackDepth ||
+        g.node4Count == 0 || g.node4Count > instanceCount) return false;
+    if (launch_tlas_fixup(g.nodes4, g.node4Count, g.leafOrder, dstNodes, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    depth4Levels = g.maxDepth4 + 1;
+    c->buildInfo.deviceBuildMs = g.deviceMs;
+    return true;
+}
+
 static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v, bool instancesOnly)
 {
     std::string berr; int r;
-    if (!instancesOnly) {
-        delete c->twoLevel; c->twoLevel = new BuiltTwoLevel();
-        if (!build_scene_two_level(s, *c->twoLevel, berr)) {
-            if (berr.find("singular") != std::string::npos) return kTwoLevelDoesNotFit;
-            return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
-        }
-    } else if (!rebuild_two_level_instances(s, *c->twoLevel, berr)) {
+    const bool timing = getenv("HRPT_BUILD_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; (void)hipStreamSynchronize(c->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[two-level] %-22s %7.3f ms\n", what, std::chrono::duration<float, std::milli>(t - tp).count()); tp = t; };
+    // who builds the tree over the instances: the GPU from 1024 instances on (host SAH: 2 / 6 / 16 ms for 4 096 / 16 384 / 65 536 instances, the GPU
+    // ~1 ms), unless the host builder was asked for (hrpt_set_bvh_builder) or HRPT_TLAS_BUILDER says otherwise
+    bool gpuTree = s.instanceCount >= 1024 && c->bvhBuilder != HRPT_BVH_BUILDER_HOST_SAH;
+    if (const char* e = getenv("HRPT_TLAS_BUILDER")) gpuTree = s.instanceCount >= 8 && (strcmp(e, "gpu") == 0 || strcmp(e, "1") == 0);
+    std::vector<float> boxes;
+    std::vector<float>* wantBoxes = gpuTree ? &boxes : nullptr;      // set: the node range of the instance tree is reserved and left empty
+    if (!instancesOnly) { delete c->twoLevel; c->twoLevel = new BuiltTwoLevel(); }
+    if (!(instancesOnly ? rebuild_two_level_instances(s, *c->twoLevel, berr, wantBoxes) : build_scene_two_level(s, *c->twoLevel, berr, wantBoxes))) {
         if (berr.find("singular") != std::string::npos) return kTwoLevelDoesNotFit;
         return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
     }
-    const BuiltTwoLevel& b = *c->twoLevel;
+    lap("host records");
+    BuiltTwoLevel& b = *c->twoLevel;
     if (two_level_stack_need(b) > 128u) return kTwoLevelDoesNotFit;
     if (!instancesOnly) {
         const HostTri* dt; const HostTriAttr* da; const HostTriTangent* dtg;
@@ -250,12 +279,31 @@ static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v,
     if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instances.data(), b.instances.size(), &di, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instShade.data(), b.instShade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
+    lap("uploads");
+    if (gpuTree) {
+        uint32_t levels = 0;
+        if (build_instance_tree_on_gpu(c, s.instanceCount, boxes, const_cast<GpuNode4*>(reinterpret_cast<const GpuNode4*>(dn4)), levels)) {
+            b.maxDepth4Tlas = levels; c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_GPU_PLOC;
+        } else {
+            // the host builds it after all: same layout rules as ever (the reserved node range shrinks to the tree's size)
+            for (void* p : c->bvhAllocations) (void)hipFree(p);
+            c->bvhAllocations.clear();
+            if (!rebuild_two_level_instances(s, b, berr)) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: " + berr);
+            if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
+            if ((r = upload(c, b.instances.data(), b.instances.size(), &di, &c->bvhAllocations)) != HRPT_OK) return r;
+            if ((r = upload(c, b.instShade.data(), b.instShade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
+            gpuTree = false;
+        }
+    }
+    lap("instance tree (GPU)");
+    if (two_level_stack_need(b) > 128u) return kTwoLevelDoesNotFit;
     v.nodes = nullptr; v.nodeCount = b.tlasNodeCount; v.rootLeaf = b.tlasRootLeaf;      // nodeCount != 0: the walk starts at node4 0 (the instance tree)
     v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)b.nodes4.size(); v.nodesQ = nullptr;
     v.instances = reinterpret_cast<const GpuInstance*>(di); v.instanceCount = (uint32_t)b.instances.size();
     v.instShade = reinterpret_cast<const GpuInstShade*>(dis);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH; c->buildInfo.structure = HRPT_ACCEL_TWO_LEVEL;
+    if (!gpuTree) c->buildInfo.usedBuilder = HRPT_BVH_BUILDER_HOST_SAH;      // (the mesh trees are the host's either way; usedBuilder names who built the tree over the instances)
+    c->buildInfo.structure = HRPT_ACCEL_TWO_LEVEL;
     c->buildInfo.instanceNodeCount = b.tlasNodeCount; c->buildInfo.distinctMeshes = b.distinctMeshes;
     c->buildInfo.triangleCount = v.triCount; c->buildInfo.nodeCount = 0; c->buildInfo.node4Count = v.node4Count;
     c->buildInfo.maxDepth = 0; c->buildInfo.maxDepth4 = b.maxDepth4Tlas + b.maxDepth4Blas;

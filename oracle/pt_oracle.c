@@ -173,10 +173,12 @@ static int32_t build_node(OrContext* c, float* cent, uint32_t first, uint32_t co
             cmn[k] = hrt_min(cmn[k], ce); cmx[k] = hrt_max(cmx[k], ce);
         }
     }
+    /* conservative padding: the fp32 triangle test may accept points a few ulp outside -- ulps of the coordinates and, for a hit next to the
+       ray origin, of the triangle's size (the shear works on vertex - origin): 1e-6 of the node's largest side covers every triangle inside */
+    float ext = hrt_max(mx[0] - mn[0], hrt_max(mx[1] - mn[1], mx[2] - mn[2]));
     for (int k = 0; k < 3; k++) {
-        /* conservative padding: the fp32 triangle test may accept points a few ulp outside */
         float m = hrt_max(hrt_abs(mn[k]), hrt_abs(mx[k]));
-        float pad = 1e-5f * m + 1e-6f;
+        float pad = 1e-5f * m + 1e-6f + 1e-6f * ext;
         n->bmin[k] = mn[k] - pad; n->bmax[k] = mx[k] + pad;
     }
     n->left = n->right = -1; n->first = first; n->count = count;

@@ -180,6 +180,30 @@ def test_two_level_update_instances_rebuilds_only_the_instance_tree(luts):
     _same_frames(luts, sc, 160, 96, 2, 4, view, pos, update=moved)
 
 
+def test_instance_tree_is_built_on_the_gpu_from_1024_instances(luts):
+    """the tree over the instances comes from the GPU builder (pt_capi.cpp build_instance_tree_on_gpu) from 1 024
+    instances on, from the host's SAH builder below that or when hrpt_set_bvh_builder asks for the host. Both trees bound the same boxes, so
+    the frames are the same bits (and the same as the flat structure's), before and after hrpt_update_instances."""
+    n = 40
+    sc = instanced_scene(luts, n, seed=21, lights="three")
+    view, pos = _camera(320, 180, n)
+    moved = sc.instances.copy()
+    rng = np.random.default_rng(2)
+    moved["m_World"][1:, 3, :3] += rng.uniform(-0.4, 0.4, (len(moved) - 1, 3)).astype(np.float32)
+    for update in (None, moved):
+        a_gpu, n_gpu, i_gpu, fb = _render(luts, sc, S.ACCEL_TWO_LEVEL, 320, 180, 2, 4, view, pos, update)
+        a_host, n_host, i_host, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, 320, 180, 2, 4, view, pos, update, builder=S.BVH_BUILDER_HOST_SAH)
+        a_flat, n_flat, _, _ = _render(luts, sc, S.ACCEL_FLAT, 320, 180, 2, 4, view, pos, update)
+        assert i_gpu.structure == S.ACCEL_TWO_LEVEL and i_gpu.usedBuilder == S.BVH_BUILDER_GPU_PLOC and fb == 0
+        assert i_host.structure == S.ACCEL_TWO_LEVEL and i_host.usedBuilder == S.BVH_BUILDER_HOST_SAH
+        assert i_gpu.instanceNodeCount == n * n + 1 > i_host.instanceNodeCount      # the GPU path reserves one node per instance (floor + n^2 of them)
+        assert n_gpu == n_host == n_flat
+        assert np.array_equal(a_gpu.view(np.uint32), a_host.view(np.uint32)) and np.array_equal(a_gpu.view(np.uint32), a_flat.view(np.uint32))
+    small = instanced_scene(luts, 12, seed=9)
+    v2, p2 = _camera(96, 64, 12)
+    assert _render(luts, small, S.ACCEL_TWO_LEVEL, 96, 64, 1, 2, v2, p2)[2].usedBuilder == S.BVH_BUILDER_HOST_SAH
+
+
 def test_two_level_matches_the_oracle(luts):
     from oracle.binding import Oracle, OrStats
     n = 6
