@@ -7,6 +7,8 @@
 #include <cstring>
 #include <future>
 #include <system_error>
+#include <thread>
+#include <atomic>
 #include <limits>
 #include <numeric>
 
@@ -268,17 +270,17 @@ bool validate_scene(const HrptSceneDesc& s, uint64_t& triCount, std::string& err
     return true;
 }
 
+// per-instance adjugate rows (TransformNormal, Common.hlsli:33-47)
+static inline void instance_shade(const float* M, HostInstShade& is)
+{
+    const float r0[3] = { M[0], M[1], M[2] }, r1[3] = { M[4], M[5], M[6] }, r2[3] = { M[8], M[9], M[10] };
+    cross3(r1, r2, is.adj0); cross3(r2, r0, is.adj1); cross3(r0, r1, is.adj2);
+    is.adj0[3] = is.adj1[3] = is.adj2[3] = 0.0f;
+}
 void build_instance_shade(const HrptSceneDesc& s, std::vector<HostInstShade>& out)
 {
-    // per-instance adjugate rows (TransformNormal, Common.hlsli:33-47)
     out.resize(s.instanceCount);
-    for (uint32_t i = 0; i < s.instanceCount; ++i) {
-        const float* M = s.instances[i].m_World;
-        const float r0[3] = { M[0], M[1], M[2] }, r1[3] = { M[4], M[5], M[6] }, r2[3] = { M[8], M[9], M[10] };
-        HostInstShade& is = out[i];
-        cross3(r1, r2, is.adj0); cross3(r2, r0, is.adj1); cross3(r0, r1, is.adj2);
-        is.adj0[3] = is.adj1[3] = is.adj2[3] = 0.0f;
-    }
+    for (uint32_t i = 0; i < s.instanceCount; ++i) instance_shade(s.instances[i].m_World, out[i]);
 }
 
 bool scene_needs_tangents(const HrptSceneDesc& s)
@@ -451,6 +453,22 @@ bool build_mesh_trees(const HrptSceneDesc& s, BuiltTwoLevel& out, std::vector<in
 }
 }
 
+// [first, last) in chunks on up to 8 host threads (a rebuild per frame over 65 k instances is 4 ms on one thread); small ranges stay on the caller's
+template <class F>
+static void for_instance_ranges(uint32_t count, F&& body)
+{
+    unsigned threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (count < 8192u) threads = 1;
+    if (threads == 1) { body(0u, count); return; }
+    std::vector<std::thread> pool;
+    const uint32_t chunk = (count + threads - 1) / threads;
+    try {
+        for (unsigned t = 1; t < threads; ++t) { const uint32_t f = std::min(count, t * chunk), l = std::min(count, f + chunk); if (f < l) pool.emplace_back([&body, f, l] { body(f, l); }); }
+    } catch (const std::system_error&) { for (std::thread& th : pool) th.join(); body(0u, count); return; }       // no threads to be had: the whole range here (idempotent)
+    body(0u, std::min(count, chunk));
+    for (std::thread& th : pool) th.join();
+}
+
 bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std::string& error, std::vector<float>* worldBoxes)
 {
     // mesh roots are recovered from the existing instance records (same mesh -> same root)
@@ -460,62 +478,81 @@ bool rebuild_two_level_instances(const HrptSceneDesc& s, BuiltTwoLevel& out, std
     // object-space bounds per mesh from its triangles (leaf-order array; inst = mesh)
     std::vector<Box> meshBox(s.meshDataCount);
     for (const HostTri& t : out.tris) { meshBox[t.inst].grow(t.p0, t.p0); meshBox[t.inst].grow(t.p1, t.p1); meshBox[t.inst].grow(t.p2, t.p2); }
-    out.instances.assign(s.instanceCount, HostInstance{});
-    std::vector<HostTri> leafSrc(s.instanceCount);
-    Builder b; BuiltBvh tl; b.src = &leafSrc; b.out = &tl; b.minLeaf = 1; b.maxLeaf = 1;
-    b.prims.resize(s.instanceCount);
-    for (uint32_t i = 0; i < s.instanceCount; ++i) {
-        const HrptPerInstanceData& in = s.instances[i];
-        HostInstance& hi = out.instances[i];
-        const float* M = in.m_World;
-        for (int r = 0; r < 4; ++r) for (int k = 0; k < 3; ++k) hi.world[3 * r + k] = M[4 * r + k];
-        if (!invert_affine(M, hi.inv)) { error = "instance " + std::to_string(i) + " has a singular world matrix: the two-level structure cannot represent it"; return false; }
-        hi.blasRoot = meshRoot[in.m_MeshDataIndex]; hi.flags = triangle_flags_for_material(s.materials[in.m_MaterialIndex]); hi.material = in.m_MaterialIndex;
-        hi.mesh = in.m_MeshDataIndex;
-        // world box: the eight corners of the mesh's object box through the flat path's transform, padded like every box
-        const Box& ob = meshBox[in.m_MeshDataIndex];
-        Box wb; float maxAbs = 0.0f;
-        if (ob.mn[0] <= ob.mx[0]) {
-            for (int c = 0; c < 8; ++c) {
-                const float p[3] = { (c & 1) ? ob.mx[0] : ob.mn[0], (c & 2) ? ob.mx[1] : ob.mn[1], (c & 4) ? ob.mx[2] : ob.mn[2] };
-                float w[3]; transform_point(p, M, w);
-                for (int k = 0; k < 3; ++k) if (!std::isfinite(w[k])) { error = "non-finite vertex position"; return false; }
-                wb.grow(w, w);
-            }
-            const float extPad = 1e-6f * std::max(wb.mx[0] - wb.mn[0], std::max(wb.mx[1] - wb.mn[1], wb.mx[2] - wb.mn[2]));      // as for triangles (triangle_extent): no triangle inside is larger
-            for (int k = 0; k < 3; ++k) {
-                maxAbs = std::max(maxAbs, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])));
-                const float pad = 1e-5f * std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + 1e-6f + extPad;
-                wb.mn[k] -= pad; wb.mx[k] += pad;
-            }
-        } else { for (int k = 0; k < 3; ++k) { wb.mn[k] = wb.mx[k] = M[12 + k]; } }
-        // a world-space vertex is rounded to binary32 after the transform; the error is mapped back to object space through |Minv| and taken
-        // eight times over
-        float invNorm = 0.0f;
-        for (int k = 0; k < 3; ++k) invNorm = std::max(invNorm, std::fabs(hi.inv[k]) + std::fabs(hi.inv[3 + k]) + std::fabs(hi.inv[6 + k]));
-        hi.invNorm = invNorm;
-        float om = 0.0f;
-        if (ob.mn[0] <= ob.mx[0]) for (int k = 0; k < 3; ++k) om = std::max(om, std::max(std::fabs(ob.mn[k]), std::fabs(ob.mx[k])));
-        hi.objMaxAbs = om * (1.0f + 1e-5f) + 1e-6f;
-        // every partial sum of transform_point is bounded by |p|max * (column sum of |M|) + |T|: three roundings of at most half an ulp of that
-        float fwdNorm = 0.0f, tMax = 0.0f;
-        for (int k = 0; k < 3; ++k) { fwdNorm = std::max(fwdNorm, std::fabs(M[k]) + std::fabs(M[4 + k]) + std::fabs(M[8 + k])); tMax = std::max(tMax, std::fabs(M[12 + k])); }
-        hi.boxEps = 8.0f * 2.4e-7f * std::max(maxAbs, om * fwdNorm + tMax) * invNorm;
-        Prim& pr = b.prims[i];
-        for (int k = 0; k < 3; ++k) { pr.bmin[k] = wb.mn[k]; pr.bmax[k] = wb.mx[k]; pr.c[k] = 0.5f * wb.mn[k] + 0.5f * wb.mx[k]; }
-        pr.tri = i; leafSrc[i].inst = i; leafSrc[i].prim = 0; leafSrc[i].flags = 0;
+    out.instances.resize(s.instanceCount);
+    out.instShade.resize(s.instanceCount);
+    std::vector<float> ownBoxes;
+    std::vector<float>& boxes = worldBoxes ? *worldBoxes : ownBoxes;       // 6 floats per instance: padded world box, min then max
+    boxes.resize((size_t)s.instanceCount * 6);
+    std::atomic<uint32_t> firstBad{ 0xFFFFFFFFu };                          // lowest instance index that cannot be represented (the error names that one, whatever the thread count)
+    auto note_bad = [&](uint32_t i) { uint32_t cur = firstBad.load(); while (i < cur && !firstBad.compare_exchange_weak(cur, i)) {} };
+    for_instance_ranges(s.instanceCount, [&](uint32_t first, uint32_t last) {
+        for (uint32_t i = first; i < last; ++i) {
+            const HrptPerInstanceData& in = s.instances[i];
+            HostInstance hi{};
+            const float* M = in.m_World;
+            for (int r = 0; r < 4; ++r) for (int k = 0; k < 3; ++k) hi.world[3 * r + k] = M[4 * r + k];
+            if (!invert_affine(M, hi.inv)) { note_bad(i); continue; }
+            hi.blasRoot = meshRoot[in.m_MeshDataIndex]; hi.flags = triangle_flags_for_material(s.materials[in.m_MaterialIndex]); hi.material = in.m_MaterialIndex;
+            hi.mesh = in.m_MeshDataIndex;
+            // world box: the eight corners of the mesh's object box through the flat path's transform, padded like every box
+            const Box& ob = meshBox[in.m_MeshDataIndex];
+            Box wb; float maxAbs = 0.0f; bool finite = true;
+            if (ob.mn[0] <= ob.mx[0]) {
+                for (int c = 0; c < 8; ++c) {
+                    const float p[3] = { (c & 1) ? ob.mx[0] : ob.mn[0], (c & 2) ? ob.mx[1] : ob.mn[1], (c & 4) ? ob.mx[2] : ob.mn[2] };
+                    float w[3]; transform_point(p, M, w);
+                    for (int k = 0; k < 3; ++k) if (!std::isfinite(w[k])) finite = false;
+                    wb.grow(w, w);
+                }
+                if (!finite) { note_bad(i); continue; }
+                const float extPad = 1e-6f * std::max(wb.mx[0] - wb.mn[0], std::max(wb.mx[1] - wb.mn[1], wb.mx[2] - wb.mn[2]));      // as for triangles (triangle_extent): no triangle inside is larger
+                for (int k = 0; k < 3; ++k) {
+                    maxAbs = std::max(maxAbs, std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])));
+                    const float pad = 1e-5f * std::max(std::fabs(wb.mn[k]), std::fabs(wb.mx[k])) + 1e-6f + extPad;
+                    wb.mn[k] -= pad; wb.mx[k] += pad;
+                }
+            } else { for (int k = 0; k < 3; ++k) { wb.mn[k] = wb.mx[k] = M[12 + k]; } }
+            // a world-space vertex is rounded to binary32 after the transform; the error is mapped back to object space through |Minv| and taken
+            // eight times over
+            float invNorm = 0.0f;
+            for (int k = 0; k < 3; ++k) invNorm = std::max(invNorm, std::fabs(hi.inv[k]) + std::fabs(hi.inv[3 + k]) + std::fabs(hi.inv[6 + k]));
+            hi.invNorm = invNorm;
+            float om = 0.0f;
+            if (ob.mn[0] <= ob.mx[0]) for (int k = 0; k < 3; ++k) om = std::max(om, std::max(std::fabs(ob.mn[k]), std::fabs(ob.mx[k])));
+            hi.objMaxAbs = om * (1.0f + 1e-5f) + 1e-6f;
+            // every partial sum of transform_point is bounded by |p|max * (column sum of |M|) + |T|: three roundings of at most half an ulp of that
+            float fwdNorm = 0.0f, tMax = 0.0f;
+            for (int k = 0; k < 3; ++k) { fwdNorm = std::max(fwdNorm, std::fabs(M[k]) + std::fabs(M[4 + k]) + std::fabs(M[8 + k])); tMax = std::max(tMax, std::fabs(M[12 + k])); }
+            hi.boxEps = 8.0f * 2.4e-7f * std::max(maxAbs, om * fwdNorm + tMax) * invNorm;
+            out.instances[i] = hi;
+            float* bx = &boxes[(size_t)i * 6];
+            for (int k = 0; k < 3; ++k) { bx[k] = wb.mn[k]; bx[3 + k] = wb.mx[k]; }
+            instance_shade(M, out.instShade[i]);
+        }
+    });
+    if (firstBad.load() != 0xFFFFFFFFu) {
+        const uint32_t i = firstBad.load();
+        float inv[12];
+        if (!invert_affine(s.instances[i].m_World, inv)) error = "instance " + std::to_string(i) + " has a singular world matrix: the two-level structure cannot represent it";
+        else error = "non-finite vertex position";
+        return false;
     }
-    build_instance_shade(s, out.instShade);
-    // the tree over the instances replaces the first tlasNodeCount nodes: rebuild the array with the mesh trees shifted if its size changes
+    // the tree over the instances occupies the first tlasNodeCount nodes: the array is put together again, mesh trees shifted, when that count changes
     std::vector<HostNode4> tlas; uint32_t dT = 0; int32_t rootLeaf = 0;
-    if (worldBoxes) {           // tree built by the caller (GPU): reserve the node range, hand out the boxes
-        worldBoxes->resize((size_t)s.instanceCount * 6);
-        for (uint32_t i = 0; i < s.instanceCount; ++i) for (int k = 0; k < 3; ++k) { (*worldBoxes)[(size_t)i * 6 + k] = b.prims[i].bmin[k]; (*worldBoxes)[(size_t)i * 6 + 3 + k] = b.prims[i].bmax[k]; }
+    if (worldBoxes) {           // tree built by the caller (GPU): the node range is reserved (one node per instance: an upper bound), its contents are the caller's
+        if (out.tlasNodeCount == s.instanceCount && out.tlasRootLeaf == 0) { out.maxDepth4Tlas = 0; return true; }      // reserved already (a rebuild): nothing moves
         HostNode4 empty{};
         for (int k = 0; k < 4; ++k) { empty.child[k] = kEmptyChild; empty.minx[k] = empty.miny[k] = empty.minz[k] = empty.maxx[k] = empty.maxy[k] = empty.maxz[k] = 1e30f; }
         tlas.assign(s.instanceCount, empty);
-    } else
-    if (s.instanceCount > 0) {
+    } else if (s.instanceCount > 0) {
+        std::vector<HostTri> leafSrc(s.instanceCount);
+        Builder b; BuiltBvh tl; b.src = &leafSrc; b.out = &tl; b.minLeaf = 1; b.maxLeaf = 1;
+        b.prims.resize(s.instanceCount);
+        for (uint32_t i = 0; i < s.instanceCount; ++i) {
+            Prim& pr = b.prims[i]; const float* bx = &boxes[(size_t)i * 6];
+            for (int k = 0; k < 3; ++k) { pr.bmin[k] = bx[k]; pr.bmax[k] = bx[3 + k]; pr.c[k] = 0.5f * bx[k] + 0.5f * bx[3 + k]; }
+            pr.tri = i; leafSrc[i].inst = i; leafSrc[i].prim = 0; leafSrc[i].flags = 0;
+        }
         Box root;
         const int32_t r = b.build(0, s.instanceCount, 0, root);
         auto inst_leaf = [&](int32_t ref) { const uint32_t first = ((uint32_t)~ref) >> 2; return ~(int32_t)(tl.tris[first].inst << 2); };

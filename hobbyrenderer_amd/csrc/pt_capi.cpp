@@ -276,7 +276,13 @@ static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v,
     }
     const HostNode4* dn4; const HostInstance* di; const HostInstShade* dis;
     if (b.nodes4.size() >= kMaxStructureNodes) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "acceleration structure: more than 2^25 nodes (32-bit node offsets in the traversal kernels)");
-    if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
+    if (gpuTree) {      // the reserved range at the front is written on the device (launch_tlas_fixup): only the mesh trees behind it cross PCIe
+        void* p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, b.nodes4.size() * sizeof(HostNode4)));
+        c->bvhAllocations.push_back(p);
+        dn4 = static_cast<const HostNode4*>(p);
+        HIP_TRY(c, hipMemcpyAsync(static_cast<HostNode4*>(p) + b.tlasNodeCount, b.nodes4.data() + b.tlasNodeCount, (b.nodes4.size() - b.tlasNodeCount) * sizeof(HostNode4), hipMemcpyHostToDevice, c->stream));
+    } else if ((r = upload(c, b.nodes4.data(), b.nodes4.size(), &dn4, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instances.data(), b.instances.size(), &di, &c->bvhAllocations)) != HRPT_OK) return r;
     if ((r = upload(c, b.instShade.data(), b.instShade.size(), &dis, &c->bvhAllocations)) != HRPT_OK) return r;
     lap("uploads");
