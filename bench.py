@@ -440,7 +440,13 @@ def main(argv=None):
                                "timed_region_GBps": all_bytes / prof_steps / (elapsed / args.steps) / 1e9,
                                "timed_region_frac": all_bytes / prof_steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
                 "kernels": kernel_times,
-                "valu": ({**valu_doc.get(kernel, {}), "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run"
+                "valu": ({**valu_doc.get(kernel, {}),
+                          # what the counters are read against: measured issue rates of a gfx950 SIMD per instruction class (cycles per wave64 instruction, >= 2 waves per SIMD)
+                          "issue_rate_reference": {"full_rate_cycles": 2.2, "half_rate_cycles": 4.2, "quarter_rate_cycles": 8.2,
+                                                   "full_rate": "v_fma/fmac/add/sub/mul_f32, v_and/or/xor, v_add/sub_u32, v_mov",
+                                                   "half_rate": "v_min/max/min3/med3, v_cmp, v_cndmask, shifts, v_cvt, v_bfe/bfi/perm, 24-bit and 32-bit integer multiplies, DPP, v_readfirstlane, v_pk_*_f32",
+                                                   "source": "profiles/r03_valu_issue_microbench.txt (scripts/microbench/valu_issue.hip)"},
+                          "source": valu_src + " (committed rocprofv3 --pmc passes of this command, not measured in this run"
                           + ("; taken at 8 of the 64 spp, and for the kernel of that name only: the shadow stage's ray generation and any-hit pass have rows of their own in the file" if args.config == 5 else "") + ")"}
                          if (valu_doc and at_baseline) else None),
                 "algorithmic_model": model,

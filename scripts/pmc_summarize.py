@@ -1,4 +1,4 @@
-"""Summarises the rocprofv3 --pmc passes of scripts/gpu_r02_pmc.sh: per kernel class VALU issue figures, LDS figures and HBM traffic per launch.
+"""Summarises the rocprofv3 --pmc passes of scripts/gpu_r03_pmc.sh: per kernel class VALU issue figures, LDS figures and HBM traffic per launch.
 Writes <out>/pmc_valu_config<N>.json, pmc_traffic_config<N>.json and a text table."""
 import collections
 import csv
