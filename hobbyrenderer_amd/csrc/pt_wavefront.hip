@@ -183,6 +183,13 @@ struct GlobalCandidates {
     HRT_DEV void key(int k, float& t, uint32_t& tri) const { uint2 v = base[k]; t = __uint_as_float(v.x); tri = v.y; }
 };
 // BVH copy in LDS; W = node width (2: GpuNode, 4: GpuNode4)
+// Stride of a 4-wide node in the LDS copy. At 128 bytes the rows of all even nodes start in the same four banks (and those of the odd nodes in four
+// others): lanes at different nodes conflict 8-fold at worst. A multiple of 32 keeps the near ^ 16 = far addressing of inner_step.
+#ifndef HRPT_LDS_NODE4_STRIDE
+#define HRPT_LDS_NODE4_STRIDE 128
+#endif
+constexpr uint32_t kLdsNode4Stride = HRPT_LDS_NODE4_STRIDE;
+static_assert(kLdsNode4Stride >= 128 && kLdsNode4Stride % 32 == 0, "LDS node stride: 128 bytes of node, near / far rows 32-byte aligned");
 template <int W>
 struct LdsBvh {
     static constexpr int kWidth = W == 5 ? 4 : W; static constexpr bool kTwoLevel = false; static constexpr bool kLds = true;
@@ -191,7 +198,7 @@ struct LdsBvh {
     HRT_DEV void tri(uint32_t i, float4& a, float4& b, float4& c) const { const float4* p = tris + 3 * i; a = p[0]; b = p[1]; c = p[2]; }
     // rows by 32-bit LDS address (the copy starts 128-byte aligned: setup_lds, so near ^ 16 is the far row of the same axis)
     typedef __attribute__((address_space(3))) const char* LdsPtr;
-    HRT_DEV uint32_t rowoff(int i, uint32_t byteOffset) const { return (uint32_t)(uintptr_t)(LdsPtr) reinterpret_cast<const char*>(nodes) + (uint32_t)i * 128u + byteOffset; }
+    HRT_DEV uint32_t rowoff(int i, uint32_t byteOffset) const { return (uint32_t)(uintptr_t)(LdsPtr) reinterpret_cast<const char*>(nodes) + (uint32_t)i * kLdsNode4Stride + byteOffset; }
     HRT_DEV float4 load(uint32_t off) const { return *reinterpret_cast<const float4*>((const char*)(LdsPtr)(uintptr_t)off); }
 };
 template <int W> struct GlobalBvhOf;
@@ -213,9 +220,11 @@ HRT_DEV void setup_lds(char* smem, const SceneView& s, LdsStack<DEPTH, LDSMAX>& 
         const float4* srcN = W == 2 ? reinterpret_cast<const float4*>(s.nodes) : reinterpret_cast<const float4*>(s.nodes4);
         const float4* srcT = reinterpret_cast<const float4*>(s.tris);
         uint32_t nN = W == 2 ? s.nodeCount * 4 : s.node4Count * 8, nT = s.triCount * 3;
-        for (uint32_t i = threadIdx.x; i < nN; i += kBlock) dst[i] = srcN[i];
-        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) dst[nN + i] = srcT[i];
-        lbvh.nodes = dst; lbvh.tris = dst + nN;
+        uint32_t nNdst = nN;                                   // float4s the node copy occupies
+        if (W == 2 || kLdsNode4Stride == 128u) { for (uint32_t i = threadIdx.x; i < nN; i += kBlock) dst[i] = srcN[i]; }
+        else { nNdst = s.node4Count * (kLdsNode4Stride / 16u); for (uint32_t i = threadIdx.x; i < nN; i += kBlock) dst[(i >> 3) * (kLdsNode4Stride / 16u) + (i & 7u)] = srcN[i]; }
+        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) dst[nNdst + i] = srcT[i];
+        lbvh.nodes = dst; lbvh.tris = dst + nNdst;
         __syncthreads();
     }
 }
@@ -1421,7 +1430,7 @@ hipError_t wavefront_trace_rays(WavefrontState& st, const SceneView& scene, cons
     const int depth = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     const size_t candBytes = shadow ? (size_t)kShadowCandidates * 2 * kBlock * 4 : 0;
     const size_t stackBytes = (size_t)(depth > kExtendLdsStack ? kExtendLdsStack : depth) * kBlock * 4;
-    const size_t bvhBytes = (size_t)scene.node4Count * 128 + (size_t)scene.triCount * 48;
+    const size_t bvhBytes = (size_t)scene.node4Count * kLdsNode4Stride + (size_t)scene.triCount * 48;
     const bool lds = !twoLevel && bvhBytes > 0 && stackBytes + candBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
     const uint32_t blocksPerCu = st.blocksPerCu ? st.blocksPerCu : 16;
     const uint64_t chunks = (count + 255) / 256, blocksNeeded = (chunks + 3) / 4;
@@ -1656,7 +1665,7 @@ hipError_t wavefront_render(WavefrontState& st, const SceneView& scene, const Sc
         if (v.width == 4 && 3 * traits.bvh4MaxDepth + 2 > kMaxStackNeed) v.width = 2;
         if (v.width == 2) v.depth = traits.bvhMaxDepth + 2 <= 8 ? 8 : (traits.bvhMaxDepth + 2 <= 16 ? 16 : (traits.bvhMaxDepth + 2 <= 32 ? 32 : 64));
         else v.depth = 3 * traits.bvh4MaxDepth + 2 <= 16 ? 16 : (3 * traits.bvh4MaxDepth + 2 <= 32 ? 32 : 64);
-        const size_t bvhBytes = (v.width == 2 ? (size_t)scene.nodeCount * 64 : (size_t)scene.node4Count * 128) + (size_t)scene.triCount * 48;
+        const size_t bvhBytes = (v.width == 2 ? (size_t)scene.nodeCount * 64 : (size_t)scene.node4Count * kLdsNode4Stride) + (size_t)scene.triCount * 48;
         const size_t stackBytes = (size_t)(v.depth > ldsStackMax ? ldsStackMax : v.depth) * kBlock * 4;
         v.lds = bvhBytes > 0 && stackBytes + extraBytes + bvhBytes <= kLdsBudget && !st.forceGlobalBvh;
         v.ldsBytes = stackBytes + (v.lds ? bvhBytes : 0) + st.padLdsBytes;
