@@ -204,6 +204,35 @@ def test_instance_tree_is_built_on_the_gpu_from_1024_instances(luts):
     assert _render(luts, small, S.ACCEL_TWO_LEVEL, 96, 64, 1, 2, v2, p2)[2].usedBuilder == S.BVH_BUILDER_HOST_SAH
 
 
+def test_instance_records_computed_on_several_host_threads(luts):
+    """From 8 192 instances on the per-instance records of a two-level build (inverse, culling slack, world box, adjugate) are computed on up
+    to eight host threads (bvh_build.cpp for_instance_ranges): 96 x 96 + 1 instances, both instance-tree builders, after a move as well --
+    the frames equal the flat structure's, and a singular matrix among them is reported for the LOWEST such instance whatever thread saw it."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    n = 96
+    sc = instanced_scene(luts, n, seed=31)
+    view, pos = _camera(256, 144, n)
+    moved = sc.instances.copy()
+    moved["m_World"][1:, 3, 0] += np.float32(0.05)
+    a_flat, n_flat, _, _ = _render(luts, sc, S.ACCEL_FLAT, 256, 144, 2, 3, view, pos, moved)
+    for builder in (None, S.BVH_BUILDER_HOST_SAH):
+        a_two, n_two, info, fb = _render(luts, sc, S.ACCEL_TWO_LEVEL, 256, 144, 2, 3, view, pos, moved, builder=builder)
+        assert info.structure == S.ACCEL_TWO_LEVEL and fb == 0 and n_two == n_flat
+        assert np.array_equal(a_two.view(np.uint32), a_flat.view(np.uint32))
+    flat = sc.instances.copy()
+    flat["m_World"][7000, 1, :] = 0.0          # instances 7000 and 3000 squashed to a plane: no inverse -> the scene is built flat
+    flat["m_World"][3000, 1, :] = 0.0
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(S.ACCEL_TWO_LEVEL)
+        c.upload_scene(sc)
+        assert c.build_info().structure == S.ACCEL_TWO_LEVEL
+        c.update_instances(flat)
+        assert c.build_info().structure == S.ACCEL_FLAT
+    finally:
+        c.close()
+
+
 def test_two_level_matches_the_oracle(luts):
     from oracle.binding import Oracle, OrStats
     n = 6
