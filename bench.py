@@ -451,9 +451,13 @@ def main(argv=None):
                          if (valu_doc and at_baseline) else None),
                 "algorithmic_model": model,
                 "queue_pool_bytes": int(pst.queuePoolBytes),
-                "note": "frac = queue bytes the dominant kernel class streams per launch / its launch time / 8 TB/s. The traversal kernel is not HBM-bound: "
-                        "its BVH is LDS- or L2-resident and it is limited by VALU / LDS issue and lane utilisation (see 'valu'); 'whole_step' is the figure "
-                        "for all kernel classes of a frame together.",
+                "note": "frac = queue bytes the dominant kernel class (largest device time in this run) streams per launch / its launch time / 8 TB/s. "
+                        + ("wf_shade is the kernel of the frame that streams: path records in, survivors and shadow entries out, and 'traffic' (PMC) next to "
+                           "the counted bytes shows how little else it fetches. " if kernel == "wf_shade" else
+                           "The traversal kernel is not HBM-bound: its BVH is LDS- or L2-resident and it is limited by VALU issue, request rate and lane "
+                           "utilisation (see 'valu'). ")
+                        + "On config 2 wf_extend and wf_shade take the same time to within 2 %, so which of the two is named here can change from run to "
+                          "run: 'kernels' has time, bytes and frac_of_hbm_peak of every class, 'whole_step' the figure for all classes of a frame together.",
             }
         else:
             # megakernel: one launch per accumulation index does the whole dispatch; its HBM traffic is the 48 B per pixel of the image streams

@@ -27,7 +27,21 @@ def test_mutated_inputs_do_not_crash_the_readers(tmp_path, seed):
     y, x = np.mgrid[0:19, 0:30]
     write_jpeg(os.path.join(d, "seed420.jpg"), np.stack([90 + 4 * x, 60 + 7 * y, 200 - 3 * x], -1), "420", restart=2)
     write_jpeg(os.path.join(d, "seed444.jpg"), np.stack([20 + 6 * x, 250 - 9 * y, 128 + 0 * x], -1), "444")
-    files = [os.path.join(d, "seed420.jpg"), os.path.join(d, "seed444.jpg"), scene_json, gltf, glb, os.path.join(d, "seed.bin"), os.path.join(d, "doc.json"), os.path.join(d, "albedo rgba.png"), os.path.join(d, "orm16.png"),
+    extra = []
+    try:                                      # progressive seeds (Pillow writes them): a whole file, and its headers with every scan cut off
+        import io
+        from PIL import Image
+        buf = io.BytesIO()
+        Image.fromarray(np.stack([90 + 4 * x, 60 + 7 * y, 200 - 3 * x], -1).astype(np.uint8)).save(buf, "JPEG", progressive=True, quality=85)
+        data = buf.getvalue()
+        sos = data.index(b"\xff\xda")
+        for name, blob in (("prog.jpg", data), ("prog_noscan.jpg", data[:sos] + b"\xff\xd9")):
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(blob)
+            extra.append(os.path.join(d, name))
+    except ImportError:
+        pass
+    files = extra + [os.path.join(d, "seed420.jpg"), os.path.join(d, "seed444.jpg"), scene_json, gltf, glb, os.path.join(d, "seed.bin"), os.path.join(d, "doc.json"), os.path.join(d, "albedo rgba.png"), os.path.join(d, "orm16.png"),
              os.path.join(d, "emissive_pal.png")]
     env = dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
     r = subprocess.run([os.path.join(CSRC, "build", "scene_fuzz"), "1500", str(seed), *files], capture_output=True, text=True, env=env, timeout=600)
