@@ -194,7 +194,8 @@ def test_instance_tree_is_built_on_the_gpu_from_1024_instances(luts):
         a_gpu, n_gpu, i_gpu, fb = _render(luts, sc, S.ACCEL_TWO_LEVEL, 320, 180, 2, 4, view, pos, update)
         a_host, n_host, i_host, _ = _render(luts, sc, S.ACCEL_TWO_LEVEL, 320, 180, 2, 4, view, pos, update, builder=S.BVH_BUILDER_HOST_SAH)
         a_flat, n_flat, _, _ = _render(luts, sc, S.ACCEL_FLAT, 320, 180, 2, 4, view, pos, update)
-        assert i_gpu.structure == S.ACCEL_TWO_LEVEL and i_gpu.usedBuilder == S.BVH_BUILDER_GPU_PLOC and fb == 0
+        # (PLOC hierarchy at upload, the Morton radix tree for the rebuild of hrpt_update_instances: pt_capi.cpp build_instance_tree_on_gpu)
+        assert i_gpu.structure == S.ACCEL_TWO_LEVEL and i_gpu.usedBuilder == (S.BVH_BUILDER_GPU_PLOC if update is None else S.BVH_BUILDER_GPU_LBVH) and fb == 0
         assert i_host.structure == S.ACCEL_TWO_LEVEL and i_host.usedBuilder == S.BVH_BUILDER_HOST_SAH
         assert i_gpu.instanceNodeCount == n * n + 1 > i_host.instanceNodeCount      # the GPU path reserves one node per instance (floor + n^2 of them)
         assert n_gpu == n_host == n_flat
