@@ -1,4 +1,4 @@
-"""The bench line's contract (the driver parses it): checked on the committed lines of the round (profiles/r02_bench_*.json, written by
+"""The bench line's contract (the driver parses it): checked on the committed lines of rounds 2 and 3 (profiles/r0N_bench_*.json, written by
 `python bench.py [--config N]` on an MI355X) and on bench.py's command line. No GPU needed."""
 import json
 import os
@@ -15,7 +15,8 @@ def _line(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name,config", [("r02_bench_n1.json", 2), ("r02_bench_config2.json", 2), ("r02_bench_config4.json", 4), ("r02_bench_config5.json", 5)])
+@pytest.mark.parametrize("name,config", [("r02_bench_n1.json", 2), ("r02_bench_config2.json", 2), ("r02_bench_config4.json", 4), ("r02_bench_config5.json", 5),
+                                         ("r03_bench_n1.json", 2), ("r03_bench_config2.json", 2), ("r03_bench_config4.json", 4), ("r03_bench_config5.json", 5)])
 def test_committed_bench_lines_keep_the_contract(name, config):
     d = _line(name)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
@@ -41,6 +42,12 @@ def test_committed_bench_lines_keep_the_contract(name, config):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
     assert d["one_frame_in_flight"]["ms_per_step"] >= d["ms_per_step"] * 0.9
+    if name.startswith("r03"):
+        # the dominant class is named from this run's times; the PMC figures it quotes are the round's own; the VALU counters say what they are read against
+        assert r["kernel"] == max(r["kernels"], key=lambda k: r["kernels"][k]["ms_per_step"])
+        assert r["traffic_source"] is None or "profiles/r03_pmc_traffic" in r["traffic_source"]
+        assert r["valu"]["issue_rate_reference"]["full_rate_cycles"] == 2.2 and r["valu"]["issue_rate_reference"]["half_rate_cycles"] == 4.2
+        assert "profiles/r03_pmc_valu" in r["valu"]["source"]
 
 
 def test_bench_command_line():
