@@ -19,6 +19,7 @@ struct GpuBuiltBvh {            // device pointers owned by the GpuBvhBuilder th
     uint32_t mortonBits = 0;    // Morton bits the hierarchy used (63, or fewer when the full-code tree was too deep)
     float sahCost = 0.0f;       // surface-area-heuristic cost of the 2-wide tree (node cost 1, triangle cost 1), root area = 1
     float deviceMs = 0.0f;      // instance upload .. last kernel
+    bool refitted = false;      // boxes refitted on the hierarchy of an earlier build (GpuBvhBuilder::refit)
     const uint32_t* leafOrder = nullptr;   // primitive (input index) at every position of the leaf order the leaf references count in
 };
 
@@ -43,7 +44,13 @@ public:
     // leafOrder only; a leaf reference ~(k << 2) names box leafOrder[k].
     hipError_t prepare_boxes(uint32_t count, hipStream_t stream, std::string& error);
     hipError_t build_boxes(const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
+    // New boxes on the hierarchy of the last successful build() / build_boxes() (same primitives, moved): no sort, no hierarchy construction.
+    // The tree stays valid whatever the motion (every box is recomputed bottom-up); its quality is that of the old topology on the new positions.
+    bool can_refit() const;
+    hipError_t refit(const HrptPerInstanceData* instances, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
+    hipError_t refit_boxes(const float* boxes, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
 private:
+    hipError_t refit_any(const HrptPerInstanceData* instances, const float* boxes, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
     hipError_t allocate(uint32_t n, const HrptSceneDesc* scene, bool needTangents, hipStream_t stream, std::string& error);
     hipError_t build_any(const HrptPerInstanceData* instances, const float* boxes, bool usePloc, uint32_t maxStackDepth, hipStream_t stream, GpuBuiltBvh& out, std::string& error);
     struct Impl;

@@ -348,7 +348,11 @@ __global__ __launch_bounds__(kB) void k_ploc_finish(BuildBuffers b, uint32_t* __
     uint32_t v = blockIdx.x * kB + threadIdx.x;
     const uint32_t n = b.triCount;
     if (v >= 2u * n - 1u) return;
-    if (v < n) { orderOut[b.finalPos[v]] = b.valB[v]; return; }          // triangles in depth-first leaf order
+    if (v < n) {                                                       // triangles in depth-first leaf order; the leaf's parent for refits (k_fit)
+        orderOut[b.finalPos[v]] = b.valB[v];
+        b.parentOfLeaf[b.finalPos[v]] = (n - 2u) - (b.pParent[v] - n);
+        return;
+    }
     uint32_t c = v - n, id = (n - 2u) - c;
     auto ref = [&](uint32_t child) { return child < n ? (b.finalPos[child] | kLeafBit) : (n - 2u) - (child - n); };
     b.childL[id] = ref(b.pL[v]); b.childR[id] = ref(b.pR[v]);
@@ -585,6 +589,8 @@ struct GpuBvhBuilder::Impl {
     bool boxes = false;                // prepare_boxes(): the primitives are boxes (one per leaf), no triangle / attribute outputs
     uint32_t maxLeaf = 0;              // 0: the default leaf size (2, HRPT_GPU_BVH_MAX_LEAF); 1 in box mode
     int lastBudget = -1; bool lastUsePloc = false;   // hierarchy attempt that fitted the stacks at the previous build(): a rebuild starts there
+    // what refit() needs of the last successful build: the buffer set as the back end saw it (final leaf order in valB), node count, 2-wide depth
+    BuildBuffers last{}; bool haveTree = false; uint32_t lastNodeCount = 0, lastMaxDepth = 0, lastBits = 0; bool lastPloc = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~Impl()
     {
@@ -699,6 +705,7 @@ hipError_t GpuBvhBuilder::build_any(const HrptPerInstanceData* instances, const 
     out = GpuBuiltBvh();
     if (!p->scratch) { error = "GPU BVH builder not prepared"; return hipErrorInvalidValue; }
     Impl& m = *p;
+    m.haveTree = false;
     hipError_t e;
     BuildBuffers b = m.b0;
     const uint32_t n = m.n;
@@ -825,6 +832,79 @@ hipError_t GpuBvhBuilder::build_any(const HrptPerInstanceData* instances, const 
         out.sahCost = ra > 0.0f ? 1.0f + sahSum / ra : 0.0f;
     }
     out.maxDepth = maxDepthSeen; out.maxDepth4 = flags[2]; out.mortonBits = (uint32_t)usedBits; out.ploc = usedPloc; out.deviceMs = ms;
+    m.last = b; m.haveTree = true; m.lastNodeCount = nodeCount; m.lastMaxDepth = maxDepthSeen; m.lastBits = (uint32_t)usedBits; m.lastPloc = usedPloc;
+    return hipSuccess;
+}
+
+// ---- refit: new boxes on the hierarchy of the last build (hrpt_refit_instances: small motions). Runs the primitive set-up, the bottom-up box fit
+// over the stored parent links, the 2-wide emission, the 4-wide collapse (its greedy choices follow the new boxes, so the 4-wide node count
+// may change) and the attribute records; skips the Morton codes, the sort, the hierarchy (the ~300 launches of PLOC) and the numbering.
+bool GpuBvhBuilder::can_refit() const { return p && p->haveTree; }
+hipError_t GpuBvhBuilder::refit(const HrptPerInstanceData* instances, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    if (!p || p->boxes || !p->haveTree) { error = "GPU BVH builder has no tree to refit"; return hipErrorInvalidValue; }
+    return refit_any(instances, nullptr, stream, out, error);
+}
+hipError_t GpuBvhBuilder::refit_boxes(const float* boxes, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    if (!p || !p->boxes || !p->haveTree) { error = "GPU BVH builder has no tree to refit"; return hipErrorInvalidValue; }
+    return refit_any(nullptr, boxes, stream, out, error);
+}
+hipError_t GpuBvhBuilder::refit_any(const HrptPerInstanceData* instances, const float* boxes, hipStream_t stream, GpuBuiltBvh& out, std::string& error)
+{
+    out = GpuBuiltBvh();
+    Impl& m = *p;
+    hipError_t e;
+    const BuildBuffers b = m.last;
+    const uint32_t n = m.n, nodeCount = m.lastNodeCount;
+    void* const prim = m.prim; size_t scanBytes = m.scanBytes;
+    auto fail = [&](hipError_t err, const char* what) { error = what; m.haveTree = false; (void)hipStreamSynchronize(stream); return err; };
+    if (m.boxes) {
+        if ((e = hipMemcpyAsync(const_cast<float*>(b.boxesIn), boxes, (size_t)n * 24, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e, "hipMemcpyAsync(GPU BVH boxes)");
+    } else {
+        for (size_t i = 0; i < m.inst.size(); ++i) std::memcpy(m.inst[i].world, instances[i].m_World, sizeof m.inst[i].world);
+        if ((e = hipMemcpyAsync(const_cast<InstRec*>(b.inst), m.inst.data(), m.inst.size() * sizeof(InstRec), hipMemcpyHostToDevice, stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync(GPU BVH instances)");
+    }
+    (void)hipEventRecord(m.ev0, stream);
+    const dim3 gT((n + kB - 1) / kB), gN((nodeCount + kB - 1) / kB), blk(kB);
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, stream, b.sceneBounds, b.flags);
+    if (m.boxes) hipLaunchKernelGGL(k_setup_boxes, gT, blk, 0, stream, b);
+    else hipLaunchKernelGGL(k_setup, gT, blk, 0, stream, b);
+    (void)hipMemsetAsync(b.visit, 0, (size_t)n * 4, stream);
+    hipLaunchKernelGGL(k_fit, gT, blk, 0, stream, b);
+    hipLaunchKernelGGL(k_emit2, gT, blk, 0, stream, b);
+    bool greedy = true;
+    if (const char* env = getenv("HRPT_GPU_BVH_COLLAPSE")) greedy = strcmp(env, "fixed") != 0;
+    (void)hipMemsetAsync(b.even, 0, (size_t)nodeCount * 4, stream);
+    hipLaunchKernelGGL(k_mark4_init, dim3(1), dim3(1), 0, stream, b);
+    for (uint32_t d = 0; d <= m.lastMaxDepth; ++d) hipLaunchKernelGGL(k_mark4, gN, blk, 0, stream, b, nodeCount, d, greedy);
+    if ((e = rocprim::exclusive_scan(prim, scanBytes, b.even, b.index4, 0u, nodeCount, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail(e, "rocprim::exclusive_scan(even)");
+    hipLaunchKernelGGL(k_emit4, gN, blk, 0, stream, b, nodeCount, greedy);
+    float* sahDev = reinterpret_cast<float*>(b.flags + 4);
+    (void)hipMemsetAsync(sahDev, 0, 4, stream);
+    hipLaunchKernelGGL(k_sah, gN, blk, 0, stream, b, nodeCount, sahDev);
+    if (!m.boxes) hipLaunchKernelGGL(k_attrs, gT, blk, 0, stream, b);
+    (void)hipEventRecord(m.ev1, stream);
+    uint32_t flags[4] = { 0, 0, 0, 0 }, tail4[2] = { 0, 0 }; float sahSum = 0.0f; GpuNode rootNode;
+    if ((e = hipMemcpyAsync(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&sahSum, sahDev, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&rootNode, b.nodes, sizeof rootNode, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&tail4[0], b.index4 + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&tail4[1], b.even + (nodeCount - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "GPU BVH refit");
+    if (flags[0]) return fail(hipErrorInvalidValue, "non-finite vertex position");
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, m.ev0, m.ev1);
+    out.nodes = b.nodes; out.nodeCount = nodeCount; out.nodes4 = b.nodes4; out.node4Count = tail4[0] + tail4[1];
+    out.tris = b.tris; out.attrs = b.attrs; out.tangents = b.tangents; out.triCount = n; out.leafOrder = b.valB;
+    {
+        float dx = std::max(rootNode.lmax[0], rootNode.rmax[0]) - std::min(rootNode.lmin[0], rootNode.rmin[0]);
+        float dy = std::max(rootNode.lmax[1], rootNode.rmax[1]) - std::min(rootNode.lmin[1], rootNode.rmin[1]);
+        float dz = std::max(rootNode.lmax[2], rootNode.rmax[2]) - std::min(rootNode.lmin[2], rootNode.rmin[2]);
+        float ra = dx * dy + dy * dz + dz * dx;
+        out.sahCost = ra > 0.0f ? 1.0f + sahSum / ra : 0.0f;
+    }
+    out.maxDepth = m.lastMaxDepth; out.maxDepth4 = flags[2]; out.mortonBits = m.lastBits; out.ploc = m.lastPloc; out.deviceMs = ms; out.refitted = true;
     return hipSuccess;
 }
 

@@ -228,7 +228,7 @@ constexpr int kTwoLevelDoesNotFit = 1;
 // builder's box mode over the instances' padded world boxes, then launch_tlas_fixup writes the nodes, leaves turned into instance references,
 // to the front of the scene's node array. The builder and its buffers stay on the device: a rebuild (hrpt_update_instances) uploads 24 bytes
 // per instance and runs the kernels. false: not built (a device error, a tree too deep): the caller builds the tree on the host instead.
-static bool build_instance_tree_on_gpu(HrptContext* c, uint32_t instanceCount, const std::vector<float>& boxes, bool rebuild, GpuNode4* dstNodes, uint32_t& depth4Levels)
+static bool build_instance_tree_on_gpu(HrptContext* c, uint32_t instanceCount, const std::vector<float>& boxes, bool rebuild, bool refit, GpuNode4* dstNodes, uint32_t& depth4Levels)
 {
     std::string gerr;
     if (!c->tlasBuilder || c->tlasBuilderInstances != instanceCount) {
@@ -242,15 +242,16 @@ static bool build_instance_tree_on_gpu(HrptContext* c, uint32_t instanceCount, c
     // moves instances every frame comes out ahead with it (update 1.8 / 4.0 ms against 3.0 / 5.5 ms), a static scene with PLOC.
     bool ploc = c->bvhBuilder == HRPT_BVH_BUILDER_GPU_PLOC || (c->bvhBuilder != HRPT_BVH_BUILDER_GPU_LBVH && !rebuild);
     if (const char* e = getenv("HRPT_TLAS_LBVH")) ploc = atoi(e) == 0;
-    if (c->tlasBuilder->build_boxes(boxes.data(), ploc, kTraversalStackDepth, c->stream, g, gerr) != hipSuccess || g.maxDepth + 2 > kTraversalStackDepth ||
-        g.node4Count == 0 || g.node4Count > instanceCount) return false;
+    const hipError_t ge = (rebuild && refit && c->tlasBuilder->can_refit()) ? c->tlasBuilder->refit_boxes(boxes.data(), c->stream, g, gerr)      // hrpt_refit_instances
+                                                                              : c->tlasBuilder->build_boxes(boxes.data(), ploc, kTraversalStackDepth, c->stream, g, gerr);
+    if (ge != hipSuccess || g.maxDepth + 2 > kTraversalStackDepth || g.node4Count == 0 || g.node4Count > instanceCount) return false;
     if (launch_tlas_fixup(g.nodes4, g.node4Count, g.leafOrder, dstNodes, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return false;
     depth4Levels = g.maxDepth4 + 1;
-    c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH;
+    c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.usedBuilder = (g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH) | (g.refitted ? HRPT_BVH_BUILDER_REFITTED : 0u);
     return true;
 }
 
-static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v, bool instancesOnly)
+static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v, bool instancesOnly, bool refit)
 {
     std::string berr; int r;
     const bool timing = getenv("HRPT_BUILD_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
@@ -295,7 +296,7 @@ static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v,
     lap("uploads");
     if (gpuTree) {
         uint32_t levels = 0;
-        if (build_instance_tree_on_gpu(c, s.instanceCount, boxes, instancesOnly, const_cast<GpuNode4*>(reinterpret_cast<const GpuNode4*>(dn4)), levels)) {
+        if (build_instance_tree_on_gpu(c, s.instanceCount, boxes, instancesOnly, refit, const_cast<GpuNode4*>(reinterpret_cast<const GpuNode4*>(dn4)), levels)) {
             b.maxDepth4Tlas = levels;
         } else {
             // the host builds it after all: same layout rules as ever (the reserved node range shrinks to the tree's size)
@@ -325,7 +326,8 @@ static int build_two_level(HrptContext* c, const HrptSceneDesc& s, SceneView& v,
     return HRPT_OK;
 }
 
-static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris, SceneView& v, bool firstBuild)
+// refit (hrpt_refit_instances): where a GPU builder holds the hierarchy of the previous build, its boxes are recomputed instead of the tree rebuilt
+static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t sceneTris, SceneView& v, bool firstBuild, bool refit = false)
 {
     const auto t0 = std::chrono::steady_clock::now();
     std::string berr;
@@ -336,7 +338,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
     const bool keepMeshTrees = !firstBuild && c->twoLevel != nullptr;       // hrpt_update_instances on a two-level scene
     free_acceleration(c, !firstBuild);
     if (keepMeshTrees || (firstBuild && two_level_wanted(c, s, sceneTris))) {
-        r = build_two_level(c, s, v, keepMeshTrees);
+        r = build_two_level(c, s, v, keepMeshTrees, refit);
         if (r != kTwoLevelDoesNotFit) {
             c->buildInfo.buildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return r;
@@ -360,7 +362,8 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
             c->gpuBuilder = new GpuBvhBuilder();
             ge = c->gpuBuilder->prepare(s, scene_needs_tangents(s), c->stream, gerr);
         }
-        if (ge == hipSuccess) ge = c->gpuBuilder->build(s.instances, builder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, c->stream, g, gerr);
+        if (ge == hipSuccess) ge = (refit && !firstBuild && c->gpuBuilder->can_refit()) ? c->gpuBuilder->refit(s.instances, c->stream, g, gerr)
+                                                                                          : c->gpuBuilder->build(s.instances, builder == HRPT_BVH_BUILDER_GPU_PLOC, kTraversalStackDepth, c->stream, g, gerr);
         if (ge == hipSuccess && g.maxDepth + 2 <= kTraversalStackDepth) {
             v.nodes = g.nodes; v.nodeCount = g.nodeCount; v.nodes4 = g.nodes4; v.node4Count = g.node4Count; v.tris = g.tris; v.triCount = g.triCount;
             v.rootLeaf = 0; v.attrs = g.attrs; v.tangents = g.tangents;
@@ -375,6 +378,7 @@ static int build_acceleration(HrptContext* c, const HrptSceneDesc& s, uint64_t s
                 v.nodes4 = reinterpret_cast<const GpuNode4*>(dn4); v.node4Count = (uint32_t)n4.size(); maxDepth4 = d4;
             }
             c->buildInfo.usedBuilder = g.ploc ? HRPT_BVH_BUILDER_GPU_PLOC : HRPT_BVH_BUILDER_GPU_LBVH; c->buildInfo.deviceBuildMs = g.deviceMs; c->buildInfo.mortonBits = g.mortonBits; c->buildInfo.sahCost = g.sahCost;
+            if (g.refitted) c->buildInfo.usedBuilder |= HRPT_BVH_BUILDER_REFITTED;
         } else {
             // too deep for the traversal stacks (or a device error): drop the device-side builder and build on the host instead
             delete c->gpuBuilder; c->gpuBuilder = nullptr;
@@ -632,7 +636,7 @@ static int update_materials_impl(HrptContext* c, const HrptMaterialConstants* ma
     return HRPT_OK;
 }
 
-static int update_instances_impl(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count)
+static int update_instances_impl(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count, bool refit)
 {
     if (!c) return HRPT_ERR_INVALID_ARGUMENT;
     if (!c->haveScene) return fail(c, HRPT_ERR_INVALID_ARGUMENT, "hrpt_update_instances: no scene uploaded");
@@ -650,7 +654,7 @@ static int update_instances_impl(HrptContext* c, const HrptPerInstanceData* inst
     HrptSceneDesc s = kept_scene_desc(c);
     const uint64_t sceneTris = kept_triangle_count(c);
     SceneView v = c->view;
-    int r = build_acceleration(c, s, sceneTris, v, false);
+    int r = build_acceleration(c, s, sceneTris, v, false, refit);
     if (r != HRPT_OK) { c->haveScene = false; return r; }   // the old tree is gone: the scene has to be uploaded again
     c->view = v;
     return HRPT_OK;
@@ -739,9 +743,15 @@ int hrpt_upload_scene(HrptContext* c, const HrptSceneDesc* s)
     catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_upload_scene: host allocation failed"); }
     catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_upload_scene: ") + e.what()); }
 }
+int hrpt_refit_instances(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count)
+{
+    try { return update_instances_impl(c, instances, firstInstance, count, true); }
+    catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_refit_instances: host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_refit_instances: ") + e.what()); }
+}
 int hrpt_update_instances(HrptContext* c, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count)
 {
-    try { return update_instances_impl(c, instances, firstInstance, count); }
+    try { return update_instances_impl(c, instances, firstInstance, count, false); }
     catch (const std::bad_alloc&) { return fail(c, HRPT_ERR_OUT_OF_MEMORY, "hrpt_update_instances: host allocation failed"); }
     catch (const std::exception& e) { return fail(c, HRPT_ERR_INVALID_ARGUMENT, std::string("hrpt_update_instances: ") + e.what()); }
 }

@@ -29,7 +29,7 @@ lib = C.CDLL(LIB_PATH)
 EXPORTS = [
     "hrpt_create", "hrpt_destroy", "hrpt_last_error", "hrpt_upload_scene", "hrpt_resize", "hrpt_render",
     "hrpt_synchronize", "hrpt_set_stream", "hrpt_get_device_images", "hrpt_read_accumulation", "hrpt_read_output",
-    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_acceleration_structure", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
+    "hrpt_write_accumulation", "hrpt_resolve_output", "hrpt_resolve_device", "hrpt_resolve_columns_device", "hrpt_get_stats", "hrpt_reset_stats", "hrpt_set_bvh_builder", "hrpt_set_acceleration_structure", "hrpt_set_shadow_overlap", "hrpt_get_build_info", "hrpt_update_instances", "hrpt_refit_instances", "hrpt_update_lights", "hrpt_update_materials", "hrpt_trace_rays", "hrpt_allgather", "hrpt_selftest_f16_decode", "hrpt_selftest_unorm8", "hrpt_selftest_bvh", "hrpt_post_process", "hrpt_read_display", "hrpt_get_exposure", "hrpt_set_exposure", "hrpt_halton",
     "hrpt_precompute_atmosphere", "hrpt_precompute_atmosphere_ex", "hrpt_atmosphere_pass",
 ]
 
@@ -58,6 +58,7 @@ lib.hrpt_allgather.argtypes = [C.POINTER(C.c_void_p), C.c_int]
 lib.hrpt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
 lib.hrpt_get_build_info.argtypes = [C.c_void_p, C.POINTER(S.BuildInfo)]
 lib.hrpt_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+lib.hrpt_refit_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.hrpt_update_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.hrpt_update_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
 lib.hrpt_reset_stats.argtypes = [C.c_void_p]
@@ -250,6 +251,13 @@ class PathTracerContext:
         instances = np.ascontiguousarray(instances)
         assert instances.dtype.itemsize == 160, "PerInstanceData records expected"
         self._check(lib.hrpt_update_instances(self._h, instances.ctypes.data, int(first), len(instances)))
+
+    def refit_instances(self, instances, first=0):
+        """update_instances for small motions: a tree built on the GPU keeps its hierarchy and gets new boxes (hrpt_refit_instances);
+        build_info().usedBuilder then carries S.BVH_BUILDER_REFITTED."""
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype.itemsize == 160, "PerInstanceData records expected"
+        self._check(lib.hrpt_refit_instances(self._h, instances.ctypes.data, int(first), len(instances)))
 
     def update_lights(self, lights):
         """Replaces the light buffer (GPULight records; the count may change)."""

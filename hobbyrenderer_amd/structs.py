@@ -143,6 +143,7 @@ class BuildInfo(C.Structure):      # HrptBuildInfo, 64 B
 
 ABI_VERSION = 3                    # HRPT_ABI_VERSION (include/hobbyrt_pt.h)
 BVH_BUILDER_HOST_SAH, BVH_BUILDER_GPU_LBVH, BVH_BUILDER_GPU_PLOC, BVH_BUILDER_AUTO = 0, 1, 2, 3
+BVH_BUILDER_REFITTED = 0x100     # ORed into BuildInfo.usedBuilder after a refit (hrpt_refit_instances)
 ACCEL_AUTO, ACCEL_FLAT, ACCEL_TWO_LEVEL = 0, 1, 2     # HRPT_ACCEL_* (hrpt_set_acceleration_structure)
 
 

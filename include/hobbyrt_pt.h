@@ -313,6 +313,7 @@ int  hrpt_get_device_images(HrptContext* ctx, void** accumulation, void** output
 #define HRPT_BVH_BUILDER_GPU_PLOC 2      /* Morton order + nearest-neighbour clustering (PLOC): better tree, a few times the LBVH build time;
                                             falls back to the LBVH hierarchy when its tree is too deep for the traversal stacks */
 #define HRPT_BVH_BUILDER_AUTO     3      /* default: HOST_SAH below 65 536 triangles, GPU_PLOC from there on */
+#define HRPT_BVH_BUILDER_REFITTED 0x100u /* ORed into HrptBuildInfo::usedBuilder when the last hrpt_refit_instances kept the hierarchy of an earlier GPU build */
 int  hrpt_set_bvh_builder(HrptContext* ctx, int builder);       /* takes effect at the next hrpt_upload_scene / hrpt_update_instances */
 typedef struct HrptBuildInfo {
     uint32_t requestedBuilder, usedBuilder;     /* HRPT_BVH_BUILDER_* */
@@ -362,6 +363,14 @@ int  hrpt_set_acceleration_structure(HrptContext* ctx, int structure);
  * PathTracerRenderer::Render's reset on a changed view matrix (src/PathTracerRenderer.cpp:41-50), restarting accumulation
  * (firstAccumulationIndex = 0) is the caller's decision. If the rebuild fails the scene is unusable until hrpt_upload_scene. */
 int  hrpt_update_instances(HrptContext* ctx, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count);
+/* The same call for SMALL motions: where a GPU builder holds the hierarchy of the previous build (flat structure built by LBVH / PLOC; the
+ * instance tree of a two-level structure from 1 024 instances on) the boxes are recomputed bottom-up on that hierarchy instead of the tree
+ * being rebuilt -- the refit of a driver's acceleration-structure update (the reference always rebuilds its TLAS,
+ * src/CommonRenderers.cpp:234-246; its BLASes are static). No sort and no hierarchy construction: a PLOC tree is refitted in a fraction of its
+ * build time and keeps its topology, so its quality follows the motion (large moves: call hrpt_update_instances). Radiance is the same
+ * either way (the hit definition does not depend on the tree). Everywhere else (host-built trees, the first call after an upload with the
+ * host builder) it IS hrpt_update_instances. HrptBuildInfo::usedBuilder carries HRPT_BVH_BUILDER_REFITTED when the hierarchy was kept. */
+int  hrpt_refit_instances(HrptContext* ctx, const HrptPerInstanceData* instances, uint32_t firstInstance, uint32_t count);
 /* The other two per-frame uploads of the reference's main loop (src/Renderer.cpp:500-507):
  * hrpt_update_lights replaces the whole light buffer, like SceneLoader::CreateAndUploadLightBuffer when Scene::m_LightsDirty is set
  * (count may differ from the uploaded scene's; at least one light; HrptPathTracerConstants::m_LightCount of later frames must not

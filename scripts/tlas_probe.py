@@ -25,13 +25,17 @@ for n in [int(a) for a in sys.argv[1:]] or [128, 256]:
         for k in range(4):
             t0 = time.perf_counter(); c.update_instances(moved if k % 2 == 0 else sc.instances); upd.append((time.perf_counter() - t0) * 1e3)
         i2 = c.build_info()
+        rf = []
+        for k in range(4):
+            t0 = time.perf_counter(); c.refit_instances(moved if k % 2 == 0 else sc.instances); rf.append((time.perf_counter() - t0) * 1e3)
+        i3 = c.build_info()
         c.render(cb, accum_count=SPP); c.synchronize()
         imgs[name + "+update"] = c.read_accumulation()
         ts = []
         for _ in range(3):
             t0 = time.perf_counter(); c.render(cb, accum_count=SPP); c.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-        print(f"{n}x{n} {name:15s}: upload {up:7.1f} ms (build {info.buildMs:6.1f}, device {info.deviceBuildMs:5.2f}) updates {' '.join(f'{u:.1f}' for u in upd)} ms (build {i2.buildMs:.1f}) "
-              f"builder {info.usedBuilder}/{i2.usedBuilder} depth4 {info.maxDepth4} nodes {info.instanceNodeCount}/{info.node4Count} frame {min(ts):.2f} ms rays {int(st.closestRays)} {int(st.shadowRays)}", flush=True)
+        print(f"{n}x{n} {name:15s}: upload {up:7.1f} ms (build {info.buildMs:6.1f}, device {info.deviceBuildMs:5.2f}) updates {' '.join(f'{u:.1f}' for u in upd)} ms (build {i2.buildMs:.1f}) refits {' '.join(f'{u:.1f}' for u in rf)} ms (device {i3.deviceBuildMs:.2f}) "
+              f"builder {info.usedBuilder}/{i2.usedBuilder}/{i3.usedBuilder} depth4 {info.maxDepth4} nodes {info.instanceNodeCount}/{info.node4Count} frame {min(ts):.2f} ms rays {int(st.closestRays)} {int(st.shadowRays)}", flush=True)
         c.close()
     for k, v in imgs.items():
         ref = imgs["flat+update" if k.endswith("+update") else "flat"]

@@ -205,6 +205,33 @@ def test_instance_tree_is_built_on_the_gpu_from_1024_instances(luts):
     assert _render(luts, small, S.ACCEL_TWO_LEVEL, 96, 64, 1, 2, v2, p2)[2].usedBuilder == S.BVH_BUILDER_HOST_SAH
 
 
+def test_instance_tree_refit(luts):
+    """hrpt_refit_instances on a two-level scene whose instance tree was built on the GPU: the tree keeps its hierarchy, the boxes follow
+    the instances (box mode of GpuBvhBuilder::refit) -- frames equal the flat structure's after small and after large moves."""
+    n = 40
+    sc = instanced_scene(luts, n, seed=23)
+    view, pos = _camera(256, 144, n)
+    from hobbyrenderer_amd.native import PathTracerContext
+    rng = np.random.default_rng(4)
+    c = PathTracerContext(0)
+    try:
+        c.set_acceleration_structure(S.ACCEL_TWO_LEVEL)
+        c.upload_scene(sc)
+        c.resize(256, 144)
+        for scale in (0.05, 3.0):
+            moved = sc.instances.copy()
+            moved["m_World"][1:, 3, :3] += rng.uniform(-scale, scale, (len(moved) - 1, 3)).astype(np.float32)
+            c.refit_instances(moved)
+            info = c.build_info()
+            assert info.structure == S.ACCEL_TWO_LEVEL and info.usedBuilder & S.BVH_BUILDER_REFITTED
+            c.render(scenes.fill_constants(view, pos, sc, 0, 3), accum_count=2, flags=S.FRAME_DEFAULT)
+            acc = c.read_accumulation()
+            a_flat, _, _, _ = _render(luts, sc, S.ACCEL_FLAT, 256, 144, 2, 3, view, pos, moved)
+            assert np.array_equal(acc.view(np.uint32), a_flat.view(np.uint32))
+    finally:
+        c.close()
+
+
 def test_instance_records_computed_on_several_host_threads(luts):
     """From 8 192 instances on the per-instance records of a two-level build (inverse, culling slack, world box, adjugate) are computed on up
     to eight host threads (bvh_build.cpp for_instance_ranges): 96 x 96 + 1 instances, both instance-tree builders, after a move as well --

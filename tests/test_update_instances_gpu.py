@@ -93,6 +93,58 @@ def test_large_textured_scene_rebuild(luts, builder):
         c.close()
 
 
+@pytest.mark.parametrize("builder", [S.BVH_BUILDER_GPU_LBVH, S.BVH_BUILDER_GPU_PLOC, S.BVH_BUILDER_HOST_SAH], ids=["lbvh", "ploc", "host"])
+def test_refit_matches_a_fresh_build(luts, builder):
+    """hrpt_refit_instances: a tree built on the GPU keeps its hierarchy and gets new boxes (no sort, no hierarchy construction) -- the
+    images are those of a scene BUILT with the new transforms all the same (the hit definition does not depend on the tree), wavefront and
+    megakernel, over several refits in a row, a rebuild in between, and LARGE moves (the refitted tree is valid whatever the motion). A
+    host-built tree has nothing to refit: the call is hrpt_update_instances there."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    sc, view, pos, cfg = scenes.config_cornell(luts, 96, 54)
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(builder)
+        c.upload_scene(sc)
+        n = len(sc.instances)
+        now = sc
+        for step, (first, count, refit) in enumerate([(n - 3, 2, True), (0, n, True), (0, n, False), (n - 2, 1, True), (0, n, True)], start=1):
+            now = _moved(now, first, count, 3 * step if step == 5 else step)
+            (c.refit_instances if refit else c.update_instances)(now.instances[first:first + count], first)
+            bi = c.build_info()
+            kept = refit and builder != S.BVH_BUILDER_HOST_SAH
+            assert bi.usedBuilder == (builder | (S.BVH_BUILDER_REFITTED if kept else 0)) and bi.triangleCount == 38
+            _assert_parity(*_render_pair(c, now, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+            _assert_parity(*_render_pair(c, now, view, pos, 96, 54, 1, 2, S.FRAME_MEGAKERNEL))
+            assert c.selftest_bvh() == 0
+    finally:
+        c.close()
+
+
+def test_refit_of_a_large_textured_scene(luts):
+    """~100 k triangles (global-memory tree, quantised nodes, tangents, MASK foliage) built by PLOC: refit after a move of half the instances,
+    every box still contains its subtree, image == oracle on a fresh scene; the refit takes a fraction of the rebuild's device time."""
+    from hobbyrenderer_amd.native import PathTracerContext
+    sc, view, pos, cfg = scenes.config_sponza_class(luts, 96, 54, detail=1.0, tex_size=32)
+    c = PathTracerContext(0)
+    try:
+        c.set_bvh_builder(S.BVH_BUILDER_GPU_PLOC)
+        c.upload_scene(sc)
+        n = len(sc.instances)
+        now = _moved(sc, n // 4, n // 2, 1)
+        c.update_instances(now.instances[n // 4:n // 4 + n // 2], n // 4)
+        rebuild_ms = c.build_info().deviceBuildMs
+        c.refit_instances(sc.instances)               # back to the original transforms on the hierarchy of the moved scene
+        bi = c.build_info()
+        assert bi.usedBuilder == (S.BVH_BUILDER_GPU_PLOC | S.BVH_BUILDER_REFITTED) and bi.triangleCount > 90000
+        assert 0 < bi.deviceBuildMs < 0.6 * rebuild_ms, (bi.deviceBuildMs, rebuild_ms)
+        assert c.selftest_bvh() == 0
+        _assert_parity(*_render_pair(c, sc, view, pos, 96, 54, 2, cfg["max_bounces"], S.FRAME_DEFAULT))
+        c.refit_instances(now.instances)
+        _assert_parity(*_render_pair(c, now, view, pos, 96, 54, 1, 3, S.FRAME_DEFAULT))
+    finally:
+        c.close()
+
+
 def test_ray_queries_follow_the_update(luts):
     from hobbyrenderer_amd.native import PathTracerContext
     from oracle.binding import Oracle
