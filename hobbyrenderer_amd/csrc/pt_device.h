@@ -278,6 +278,10 @@ HRT_DEV float slab1(float bminx, float bminy, float bminz, float bmaxx, float bm
     bool hit = __builtin_fmaf(-__builtin_fabsf(lo), 2e-6f, lo) <= __builtin_fmaf(__builtin_fabsf(hi), 2e-6f, hi);
     return hit ? lo : __builtin_inff();
 }
+// Compare-swap of two (entry distance, child) pairs: the pair with the smaller distance ends up in (ta, ra). One compare + four selects, all
+// half-rate instructions on gfx950, and the five swaps of a node step are 25 of its 70 half-rate instructions -- but the integer form (mask
+// (ib - ia) >> 31 of the bit patterns, masked XOR exchange: one shift + five full-rate integer / v_bitop3 operations) measured 4 % SLOWER on
+// configs 2 and 4: full-rate integer and logic operations do not overlap with half-rate ones the way FMAs do.
 HRT_DEV void cswap(float& ta, int32_t& ra, float& tb, int32_t& rb)
 {
     bool sw = tb < ta;

@@ -32,7 +32,7 @@ struct WaveRecord { unsigned long long ticks, realticks; unsigned int hwid, xcc;
 #define R16(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
 #define ACC_OPERANDS "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
 
-enum Op { OP_FMA, OP_FMAC, OP_ADD, OP_SUB, OP_MUL, OP_MAX, OP_MIN3, OP_MED3, OP_CNDMASK, OP_CNDMASK_SWAP, OP_CNDMASK_SGPR, OP_CMP, OP_CMP_SGPR, OP_CMP_CNDMASK, OP_CMP_4CND, OP_CMPS_4CND, OP_CMP_4CND_DEP, OP_CMP_3FMA_CND, OP_CND_FMA_ALT, OP_CMP_CND_FMA_CND, OP_CMP_CND_3FMA_CND, OP_CND_E64_VCC, OP_CND_NOP, OP_CND_E32_E64_ALT, OP_CMP_4CND_E64VCC, OP_CMP_CND_NOP4, OP_DIVFMAS, OP_ADDC, OP_CND2_FMA2, OP_CND3_FMA, OP_CND2_MAX2, OP_CMP_CND2_FMA, OP_AND, OP_OR, OP_XOR, OP_LSHL, OP_ADDU, OP_SUBU, OP_MINU, OP_MAXI, OP_LSHL_ADD, OP_AND_OR, OP_BFI, OP_BFE, OP_PERM, OP_MUL24, OP_MAD24, OP_MULLO, OP_CVT, OP_MOV, OP_MOV_DPP, OP_READLANE, OP_PKFMA, OP_PKMUL, OP_RCP, OP_MIX_FMA_MAX, OP_MIX_FMA_CMP, OP_DSREAD, OP_COUNT };
+enum Op { OP_FMA, OP_FMAC, OP_ADD, OP_SUB, OP_MUL, OP_MAX, OP_MIN3, OP_MED3, OP_CNDMASK, OP_CNDMASK_SWAP, OP_CNDMASK_SGPR, OP_CMP, OP_CMP_SGPR, OP_CMP_CNDMASK, OP_CMP_4CND, OP_CMPS_4CND, OP_CMP_4CND_DEP, OP_CMP_3FMA_CND, OP_CND_FMA_ALT, OP_CMP_CND_FMA_CND, OP_CMP_CND_3FMA_CND, OP_CND_E64_VCC, OP_CND_NOP, OP_CND_E32_E64_ALT, OP_CMP_4CND_E64VCC, OP_CMP_CND_NOP4, OP_DIVFMAS, OP_ADDC, OP_CND2_FMA2, OP_CND3_FMA, OP_CND2_MAX2, OP_CMP_CND2_FMA, OP_AND, OP_OR, OP_XOR, OP_LSHL, OP_ADDU, OP_SUBU, OP_MINU, OP_MAXI, OP_LSHL_ADD, OP_AND_OR, OP_BFI, OP_BFE, OP_PERM, OP_MUL24, OP_MAD24, OP_MULLO, OP_CVT, OP_MOV, OP_MOV_DPP, OP_READLANE, OP_PKFMA, OP_PKMUL, OP_RCP, OP_MIX_FMA_MAX, OP_MIX_FMA_CMP, OP_DSREAD, OP_BITOP3, OP_ASHR, OP_MIX_BITOP3_MAX, OP_MIX_AND_MAX, OP_MIX_ADDU_MAX, OP_MIX_MULF_MAX, OP_MIX_XOR_CND, OP_COUNT };
 static const char* kOpName[OP_COUNT] = {
     "v_fma_f32 (VOP3, 3 VGPR srcs)",
     "v_fmac_f32 (VOP2)",
@@ -91,7 +91,14 @@ static const char* kOpName[OP_COUNT] = {
     "v_rcp_f32 (transcendental)",
     "mix: 8 x (v_fma_f32, v_max_f32) alternating",
     "mix: 8 x (v_fma_f32, v_cmp_lt_f32) alternating",
-    "ds_read_b32 (per-lane column, conflict-free) + waitcnt per 16" };
+    "ds_read_b32 (per-lane column, conflict-free) + waitcnt per 16",
+    "v_bitop3_b32 (VOP3, three-input bit operation 0x6c)",
+    "v_ashrrev_i32 (VOP2)",
+    "mix: 8 x (v_bitop3_b32, v_max_f32) alternating",
+    "mix: 8 x (v_and_b32, v_max_f32) alternating",
+    "mix: 8 x (v_add_u32, v_max_f32) alternating",
+    "mix: 8 x (v_mul_f32, v_max_f32) alternating",
+    "mix: 8 x (v_xor_b32, v_cndmask_b32_e64 s[20:21]) alternating" };
 
 template <int OP>
 __global__ __launch_bounds__(256) void issue_loop(WaveRecord* rec, float* sink, int iters, float fb, float fc)
@@ -215,6 +222,20 @@ __global__ __launch_bounds__(256) void issue_loop(WaveRecord* rec, float* sink, 
                 asm volatile("v_and_or_b32 %0, %0, %16, %17\n" "v_and_or_b32 %1, %1, %16, %17\n" "v_and_or_b32 %2, %2, %16, %17\n" "v_and_or_b32 %3, %3, %16, %17\n" "v_and_or_b32 %4, %4, %16, %17\n" "v_and_or_b32 %5, %5, %16, %17\n" "v_and_or_b32 %6, %6, %16, %17\n" "v_and_or_b32 %7, %7, %16, %17\n" "v_and_or_b32 %8, %8, %16, %17\n" "v_and_or_b32 %9, %9, %16, %17\n" "v_and_or_b32 %10, %10, %16, %17\n" "v_and_or_b32 %11, %11, %16, %17\n" "v_and_or_b32 %12, %12, %16, %17\n" "v_and_or_b32 %13, %13, %16, %17\n" "v_and_or_b32 %14, %14, %16, %17\n" "v_and_or_b32 %15, %15, %16, %17\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
             } else if constexpr (OP == OP_BFI) {
                 asm volatile("v_bfi_b32 %0, %16, %0, %17\n" "v_bfi_b32 %1, %16, %1, %17\n" "v_bfi_b32 %2, %16, %2, %17\n" "v_bfi_b32 %3, %16, %3, %17\n" "v_bfi_b32 %4, %16, %4, %17\n" "v_bfi_b32 %5, %16, %5, %17\n" "v_bfi_b32 %6, %16, %6, %17\n" "v_bfi_b32 %7, %16, %7, %17\n" "v_bfi_b32 %8, %16, %8, %17\n" "v_bfi_b32 %9, %16, %9, %17\n" "v_bfi_b32 %10, %16, %10, %17\n" "v_bfi_b32 %11, %16, %11, %17\n" "v_bfi_b32 %12, %16, %12, %17\n" "v_bfi_b32 %13, %16, %13, %17\n" "v_bfi_b32 %14, %16, %14, %17\n" "v_bfi_b32 %15, %16, %15, %17\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_BITOP3) {
+                asm volatile("v_bitop3_b32 %0, %0, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %1, %1, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %2, %2, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %3, %3, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %4, %4, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %5, %5, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %6, %6, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %7, %7, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %8, %8, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %9, %9, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %10, %10, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %11, %11, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %12, %12, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %13, %13, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %14, %14, %16, %17 bitop3:0x6c\n" "v_bitop3_b32 %15, %15, %16, %17 bitop3:0x6c\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_ASHR) {
+                asm volatile("v_ashrrev_i32 %0, 1, %0\n" "v_ashrrev_i32 %1, 1, %1\n" "v_ashrrev_i32 %2, 1, %2\n" "v_ashrrev_i32 %3, 1, %3\n" "v_ashrrev_i32 %4, 1, %4\n" "v_ashrrev_i32 %5, 1, %5\n" "v_ashrrev_i32 %6, 1, %6\n" "v_ashrrev_i32 %7, 1, %7\n" "v_ashrrev_i32 %8, 1, %8\n" "v_ashrrev_i32 %9, 1, %9\n" "v_ashrrev_i32 %10, 1, %10\n" "v_ashrrev_i32 %11, 1, %11\n" "v_ashrrev_i32 %12, 1, %12\n" "v_ashrrev_i32 %13, 1, %13\n" "v_ashrrev_i32 %14, 1, %14\n" "v_ashrrev_i32 %15, 1, %15\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_MIX_BITOP3_MAX) {
+                asm volatile("v_bitop3_b32 %0, %0, %16, %17 bitop3:0x6c\n" "v_max_f32 %1, %1, %16\n" "v_bitop3_b32 %2, %2, %16, %17 bitop3:0x6c\n" "v_max_f32 %3, %3, %16\n" "v_bitop3_b32 %4, %4, %16, %17 bitop3:0x6c\n" "v_max_f32 %5, %5, %16\n" "v_bitop3_b32 %6, %6, %16, %17 bitop3:0x6c\n" "v_max_f32 %7, %7, %16\n" "v_bitop3_b32 %8, %8, %16, %17 bitop3:0x6c\n" "v_max_f32 %9, %9, %16\n" "v_bitop3_b32 %10, %10, %16, %17 bitop3:0x6c\n" "v_max_f32 %11, %11, %16\n" "v_bitop3_b32 %12, %12, %16, %17 bitop3:0x6c\n" "v_max_f32 %13, %13, %16\n" "v_bitop3_b32 %14, %14, %16, %17 bitop3:0x6c\n" "v_max_f32 %15, %15, %16\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_MIX_AND_MAX) {
+                asm volatile("v_and_b32 %0, %0, %16\n" "v_max_f32 %1, %1, %16\n" "v_and_b32 %2, %2, %16\n" "v_max_f32 %3, %3, %16\n" "v_and_b32 %4, %4, %16\n" "v_max_f32 %5, %5, %16\n" "v_and_b32 %6, %6, %16\n" "v_max_f32 %7, %7, %16\n" "v_and_b32 %8, %8, %16\n" "v_max_f32 %9, %9, %16\n" "v_and_b32 %10, %10, %16\n" "v_max_f32 %11, %11, %16\n" "v_and_b32 %12, %12, %16\n" "v_max_f32 %13, %13, %16\n" "v_and_b32 %14, %14, %16\n" "v_max_f32 %15, %15, %16\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_MIX_ADDU_MAX) {
+                asm volatile("v_add_u32 %0, %0, %16\n" "v_max_f32 %1, %1, %16\n" "v_add_u32 %2, %2, %16\n" "v_max_f32 %3, %3, %16\n" "v_add_u32 %4, %4, %16\n" "v_max_f32 %5, %5, %16\n" "v_add_u32 %6, %6, %16\n" "v_max_f32 %7, %7, %16\n" "v_add_u32 %8, %8, %16\n" "v_max_f32 %9, %9, %16\n" "v_add_u32 %10, %10, %16\n" "v_max_f32 %11, %11, %16\n" "v_add_u32 %12, %12, %16\n" "v_max_f32 %13, %13, %16\n" "v_add_u32 %14, %14, %16\n" "v_max_f32 %15, %15, %16\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_MIX_MULF_MAX) {
+                asm volatile("v_mul_f32 %0, %0, %16\n" "v_max_f32 %1, %1, %16\n" "v_mul_f32 %2, %2, %16\n" "v_max_f32 %3, %3, %16\n" "v_mul_f32 %4, %4, %16\n" "v_max_f32 %5, %5, %16\n" "v_mul_f32 %6, %6, %16\n" "v_max_f32 %7, %7, %16\n" "v_mul_f32 %8, %8, %16\n" "v_max_f32 %9, %9, %16\n" "v_mul_f32 %10, %10, %16\n" "v_max_f32 %11, %11, %16\n" "v_mul_f32 %12, %12, %16\n" "v_max_f32 %13, %13, %16\n" "v_mul_f32 %14, %14, %16\n" "v_max_f32 %15, %15, %16\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
+            } else if constexpr (OP == OP_MIX_XOR_CND) {
+                asm volatile("v_xor_b32 %0, %0, %16\n" "v_cndmask_b32_e64 %1, %1, %16, s[20:21]\n" "v_xor_b32 %2, %2, %16\n" "v_cndmask_b32_e64 %3, %3, %16, s[20:21]\n" "v_xor_b32 %4, %4, %16\n" "v_cndmask_b32_e64 %5, %5, %16, s[20:21]\n" "v_xor_b32 %6, %6, %16\n" "v_cndmask_b32_e64 %7, %7, %16, s[20:21]\n" "v_xor_b32 %8, %8, %16\n" "v_cndmask_b32_e64 %9, %9, %16, s[20:21]\n" "v_xor_b32 %10, %10, %16\n" "v_cndmask_b32_e64 %11, %11, %16, s[20:21]\n" "v_xor_b32 %12, %12, %16\n" "v_cndmask_b32_e64 %13, %13, %16, s[20:21]\n" "v_xor_b32 %14, %14, %16\n" "v_cndmask_b32_e64 %15, %15, %16, s[20:21]\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
             } else if constexpr (OP == OP_BFE) {
                 asm volatile("v_bfe_u32 %0, %0, 3, 7\n" "v_bfe_u32 %1, %1, 3, 7\n" "v_bfe_u32 %2, %2, 3, 7\n" "v_bfe_u32 %3, %3, 3, 7\n" "v_bfe_u32 %4, %4, 3, 7\n" "v_bfe_u32 %5, %5, 3, 7\n" "v_bfe_u32 %6, %6, 3, 7\n" "v_bfe_u32 %7, %7, 3, 7\n" "v_bfe_u32 %8, %8, 3, 7\n" "v_bfe_u32 %9, %9, 3, 7\n" "v_bfe_u32 %10, %10, 3, 7\n" "v_bfe_u32 %11, %11, 3, 7\n" "v_bfe_u32 %12, %12, 3, 7\n" "v_bfe_u32 %13, %13, 3, 7\n" "v_bfe_u32 %14, %14, 3, 7\n" "v_bfe_u32 %15, %15, 3, 7\n" : ACC_OPERANDS : "v"(ib), "v"(ic) : "vcc", "s20", "s21");
             } else if constexpr (OP == OP_PERM) {
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256) void issue_loop(WaveRecord* rec, float* sink, 
 }
 
 typedef void (*Kernel)(WaveRecord*, float*, int, float, float);
-static Kernel kKernels[OP_COUNT] = { issue_loop<OP_FMA>, issue_loop<OP_FMAC>, issue_loop<OP_ADD>, issue_loop<OP_SUB>, issue_loop<OP_MUL>, issue_loop<OP_MAX>, issue_loop<OP_MIN3>, issue_loop<OP_MED3>, issue_loop<OP_CNDMASK>, issue_loop<OP_CNDMASK_SWAP>, issue_loop<OP_CNDMASK_SGPR>, issue_loop<OP_CMP>, issue_loop<OP_CMP_SGPR>, issue_loop<OP_CMP_CNDMASK>, issue_loop<OP_CMP_4CND>, issue_loop<OP_CMPS_4CND>, issue_loop<OP_CMP_4CND_DEP>, issue_loop<OP_CMP_3FMA_CND>, issue_loop<OP_CND_FMA_ALT>, issue_loop<OP_CMP_CND_FMA_CND>, issue_loop<OP_CMP_CND_3FMA_CND>, issue_loop<OP_CND_E64_VCC>, issue_loop<OP_CND_NOP>, issue_loop<OP_CND_E32_E64_ALT>, issue_loop<OP_CMP_4CND_E64VCC>, issue_loop<OP_CMP_CND_NOP4>, issue_loop<OP_DIVFMAS>, issue_loop<OP_ADDC>, issue_loop<OP_CND2_FMA2>, issue_loop<OP_CND3_FMA>, issue_loop<OP_CND2_MAX2>, issue_loop<OP_CMP_CND2_FMA>, issue_loop<OP_AND>, issue_loop<OP_OR>, issue_loop<OP_XOR>, issue_loop<OP_LSHL>, issue_loop<OP_ADDU>, issue_loop<OP_SUBU>, issue_loop<OP_MINU>, issue_loop<OP_MAXI>, issue_loop<OP_LSHL_ADD>, issue_loop<OP_AND_OR>, issue_loop<OP_BFI>, issue_loop<OP_BFE>, issue_loop<OP_PERM>, issue_loop<OP_MUL24>, issue_loop<OP_MAD24>, issue_loop<OP_MULLO>, issue_loop<OP_CVT>, issue_loop<OP_MOV>, issue_loop<OP_MOV_DPP>, issue_loop<OP_READLANE>, issue_loop<OP_PKFMA>, issue_loop<OP_PKMUL>, issue_loop<OP_RCP>, issue_loop<OP_MIX_FMA_MAX>, issue_loop<OP_MIX_FMA_CMP>, issue_loop<OP_DSREAD> };
+static Kernel kKernels[OP_COUNT] = { issue_loop<OP_FMA>, issue_loop<OP_FMAC>, issue_loop<OP_ADD>, issue_loop<OP_SUB>, issue_loop<OP_MUL>, issue_loop<OP_MAX>, issue_loop<OP_MIN3>, issue_loop<OP_MED3>, issue_loop<OP_CNDMASK>, issue_loop<OP_CNDMASK_SWAP>, issue_loop<OP_CNDMASK_SGPR>, issue_loop<OP_CMP>, issue_loop<OP_CMP_SGPR>, issue_loop<OP_CMP_CNDMASK>, issue_loop<OP_CMP_4CND>, issue_loop<OP_CMPS_4CND>, issue_loop<OP_CMP_4CND_DEP>, issue_loop<OP_CMP_3FMA_CND>, issue_loop<OP_CND_FMA_ALT>, issue_loop<OP_CMP_CND_FMA_CND>, issue_loop<OP_CMP_CND_3FMA_CND>, issue_loop<OP_CND_E64_VCC>, issue_loop<OP_CND_NOP>, issue_loop<OP_CND_E32_E64_ALT>, issue_loop<OP_CMP_4CND_E64VCC>, issue_loop<OP_CMP_CND_NOP4>, issue_loop<OP_DIVFMAS>, issue_loop<OP_ADDC>, issue_loop<OP_CND2_FMA2>, issue_loop<OP_CND3_FMA>, issue_loop<OP_CND2_MAX2>, issue_loop<OP_CMP_CND2_FMA>, issue_loop<OP_AND>, issue_loop<OP_OR>, issue_loop<OP_XOR>, issue_loop<OP_LSHL>, issue_loop<OP_ADDU>, issue_loop<OP_SUBU>, issue_loop<OP_MINU>, issue_loop<OP_MAXI>, issue_loop<OP_LSHL_ADD>, issue_loop<OP_AND_OR>, issue_loop<OP_BFI>, issue_loop<OP_BFE>, issue_loop<OP_PERM>, issue_loop<OP_MUL24>, issue_loop<OP_MAD24>, issue_loop<OP_MULLO>, issue_loop<OP_CVT>, issue_loop<OP_MOV>, issue_loop<OP_MOV_DPP>, issue_loop<OP_READLANE>, issue_loop<OP_PKFMA>, issue_loop<OP_PKMUL>, issue_loop<OP_RCP>, issue_loop<OP_MIX_FMA_MAX>, issue_loop<OP_MIX_FMA_CMP>, issue_loop<OP_DSREAD>, issue_loop<OP_BITOP3>, issue_loop<OP_ASHR>, issue_loop<OP_MIX_BITOP3_MAX>, issue_loop<OP_MIX_AND_MAX>, issue_loop<OP_MIX_ADDU_MAX>, issue_loop<OP_MIX_MULF_MAX>, issue_loop<OP_MIX_XOR_CND> };
 
 int main(int argc, char** argv)
 {
