@@ -25,3 +25,5 @@ out=$(env HRPT_TEST_TWO_LEVEL_SEEDS=300 timeout -k 10 1000 python -m pytest test
 echo "two-level structure against the flat one (random instanced scenes: opaque / textured / MASK / glass / stochastic alpha, 1 or 3 lights, up to 4000 units from the origin): 300 scenes: $out"
 out=$(env HRPT_TEST_TWO_LEVEL_SEEDS=150 HRPT_TLAS_BUILDER=gpu timeout -k 10 1000 python -m pytest tests/test_two_level_gpu.py -x -q -k random_scenes 2>&1 | tail -1)
 echo "the same with the instance tree built on the GPU whatever the instance count (HRPT_TLAS_BUILDER=gpu): 150 scenes: $out"
+out=$(env HRPT_TEST_REFIT_SEEDS=300 timeout -k 10 1000 python -m pytest tests/test_parity_gpu.py -x -q -k after_a_refit 2>&1 | tail -1)
+echo "hrpt_refit_instances on random scenes (every instance moved, PLOC / LBVH hierarchies kept), wavefront and megakernel against the oracle on a fresh scene: 300 scenes: $out"

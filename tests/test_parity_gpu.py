@@ -143,6 +143,47 @@ def test_random_material_subsets_wavefront_equals_megakernel_and_oracle(ctx, lut
             assert np.array_equal(wf.view(np.uint32), oacc.view(np.uint32)), f"seed {seed} vs oracle: material classes {classes}, light set {lights}"
 
 
+def test_random_scenes_after_a_refit_equal_the_oracle(luts):
+    """hrpt_refit_instances on random trait scenes (the generator above; 400 triangles: GPU-built trees): every instance is rotated and
+    shifted, the tree of the ORIGINAL positions gets new boxes (PLOC and LBVH hierarchies alternate), and wavefront and megakernel must
+    both equal the oracle's image of a scene built from the moved instances. 12 scenes (HRPT_TEST_REFIT_SEEDS for more)."""
+    import copy, math, os
+    from hobbyrenderer_amd.native import PathTracerContext
+    from oracle.binding import Oracle
+    from scene_helpers import random_trait_scene
+    w, h, spp, bounces = 48, 32, 2, 5
+    view, pos = scenes.planar_view(w, h, position=(0.2, 0.3, -5.0), aspect=w / h)
+    for seed in range(int(os.environ.get("HRPT_TEST_REFIT_SEEDS", "12"))):
+        sc, classes, lights = random_trait_scene(luts, 1000 + seed, 400)
+        rng = np.random.default_rng(seed)
+        moved = copy.copy(sc)
+        inst = sc.instances.copy()
+        for k in range(len(inst)):
+            a = rng.uniform(-0.6, 0.6)
+            rot = np.array([[math.cos(a), 0, -math.sin(a), 0], [0, 1, 0, 0], [math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]], np.float64)
+            shift = np.eye(4); shift[3, :3] = rng.uniform(-0.25, 0.25, 3)
+            inst["m_World"][k] = (inst["m_World"][k].reshape(4, 4).astype(np.float64) @ rot @ shift).astype(np.float32).reshape(inst["m_World"][k].shape)
+        moved.instances = inst
+        c = PathTracerContext(0)
+        try:
+            builder = S.BVH_BUILDER_GPU_PLOC if seed % 2 == 0 else S.BVH_BUILDER_GPU_LBVH
+            c.set_bvh_builder(builder)
+            c.upload_scene(sc)
+            c.refit_instances(moved.instances)
+            assert c.build_info().usedBuilder == (builder | S.BVH_BUILDER_REFITTED), seed
+            assert c.selftest_bvh() == 0, seed
+            cb = scenes.fill_constants(view, pos, moved, 0, bounces)
+            c.resize(w, h); c.render(cb, accum_count=spp, flags=S.FRAME_WAVEFRONT); wf = c.read_accumulation()
+            c.resize(w, h); c.render(cb, accum_count=spp, flags=S.FRAME_MEGAKERNEL); mk = c.read_accumulation()
+        finally:
+            c.close()
+        o = Oracle(moved)
+        oacc, _ = o.render_accumulated(lambda i: scenes.fill_constants(view, pos, moved, i, bounces), w, h, spp)
+        o.close()
+        assert np.array_equal(wf.view(np.uint32), oacc.view(np.uint32)), f"seed {seed}: wavefront after refit vs oracle; material classes {classes}, light set {lights}"
+        assert np.array_equal(mk.view(np.uint32), oacc.view(np.uint32)), f"seed {seed}: megakernel after refit vs oracle"
+
+
 def test_wavefront_equals_megakernel_full_config2(ctx, luts):
     """BASELINE config 2 at full size (1920x1080, 8 spp, 4 bounces): the oracle is too slow for the whole frame in a
     unit test, so the two independent GPU schedules (validation megakernel, wavefront pipeline) are compared bit for
